@@ -1,0 +1,82 @@
+"""Policy/value network of the bin-packing evaluator (IMPALA-style CNN).
+
+Architecture and parameter names follow the reference so that its checkpoints
+(`{'state_dict': ...}` with `conv_seqs.{0,1,2}.{conv,res_block{0,1}.conv{0,1}}`,
+`hidden_fc`, `logits_fc`, `value_fc`) load unchanged:
+reference xw_mcts/binpacking/pytorch/BinpackingNNet.py:15-81.
+
+    3 x [conv3x3(pad 1) -> maxpool(3, stride 2, pad 1) -> 2 x residual(relu,conv,relu,conv,+skip)]
+    with 16/32/32 channels -> flatten -> relu -> fc 256 -> relu -> {fc A -> log_softmax, fc 1 -> tanh}
+
+The module is FP32 only (the parity bar is 1e-5 against the CPU reference); it
+is the body that `NNetWrapper` and the batched evaluator run on PyTorch-ROCm.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+STAGE_CHANNELS = (16, 32, 32)
+HIDDEN = 256
+
+
+def _conv3x3(cin, cout):
+    return nn.Conv2d(cin, cout, kernel_size=3, padding=1)
+
+
+class _Residual(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv0 = _conv3x3(ch, ch)
+        self.conv1 = _conv3x3(ch, ch)
+
+    def forward(self, x):
+        y = self.conv0(F.relu(x))
+        y = self.conv1(F.relu(y))
+        return y + x
+
+
+class _Stage(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _conv3x3(cin, cout)
+        self.res_block0 = _Residual(cout)
+        self.res_block1 = _Residual(cout)
+
+    def forward(self, x):
+        x = F.max_pool2d(self.conv(x), kernel_size=3, stride=2, padding=1)
+        return self.res_block1(self.res_block0(x))
+
+
+def stage_shapes(in_planes, board_h, board_w):
+    """[(C, H, W)] after each stage; spatial size halves rounding up."""
+    out, h, w = [], board_h, board_w
+    for ch in STAGE_CHANNELS:
+        h, w = (h + 1) // 2, (w + 1) // 2
+        out.append((ch, h, w))
+    return out
+
+
+class BinPackingNNet(nn.Module):
+    def __init__(self, game, args):
+        super().__init__()
+        self.board_h, self.board_w = game.getBoardSize()
+        self.action_size = game.getActionSize()
+        self.args = args
+        self.in_channels = int(args.num_items) + int(args.num_bins)
+        shapes = stage_shapes(self.in_channels, self.board_h, self.board_w)
+        cins = (self.in_channels,) + STAGE_CHANNELS[:-1]
+        self.conv_seqs = nn.ModuleList(_Stage(ci, co) for ci, co in zip(cins, STAGE_CHANNELS))
+        c, h, w = shapes[-1]
+        self.hidden_fc = nn.Linear(c * h * w, HIDDEN)
+        self.logits_fc = nn.Linear(HIDDEN, self.action_size)
+        self.value_fc = nn.Linear(HIDDEN, 1)
+
+    def trunk(self, x):
+        for stage in self.conv_seqs:
+            x = stage(x)
+        x = F.relu(torch.flatten(x, start_dim=1))
+        return F.relu(self.hidden_fc(x))
+
+    def forward(self, x):
+        z = self.trunk(x)
+        return F.log_softmax(self.logits_fc(z), dim=1), torch.tanh(self.value_fc(z))

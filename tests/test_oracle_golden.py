@@ -1,0 +1,141 @@
+"""The CPU oracle (oracle/rp_oracle.c) against golden vectors captured from the
+imported Python reference (tests/golden/make_golden.py).  Bit-exact everywhere."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import evaluators as ev
+import oracle_lib as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_np_pairwise_sum_matches_numpy():
+    rng = np.random.default_rng(0)
+    for n in [1, 3, 7, 8, 9, 50, 80, 100, 128, 129, 150, 250, 640, 1000, 2500, 6400]:
+        for _ in range(40):
+            a = rng.random(n) * (rng.random(n) < 0.3)
+            assert orc.np_sum(a) == np.sum(a)
+            b = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)
+            assert orc.np_sum(b) == np.sum(b)
+
+
+@pytest.fixture(scope="module")
+def rules():
+    return np.load(os.path.join(GOLDEN, "game_rules.npz"))
+
+
+def test_valid_moves_and_next_state_match_reference(rules):
+    g = rules
+    n = len(g["W"])
+    assert n > 600
+    for i in range(n):
+        W, H, N = int(g["W"][i]), int(g["H"][i]), int(g["N"][i])
+        A = W * N
+        board = ev.unpack_board(g["rows"][i, :H], W)
+        iw, ih, rem = g["iw"][i, :N], g["ih"][i, :N], g["rem"][i, :N]
+        # a placed item's plane gives w = h = 0 in the fixture; the oracle never reads them
+        want = np.unpackbits(g["valid_bits"][i], bitorder="little")[:A]
+        got, cnt = orc.valid_moves(W, H, N, board, iw, ih, rem)
+        assert np.array_equal(got, want), i
+        assert cnt == want.sum()
+        assert orc.has_valid_moves(W, H, N, board, iw, ih, rem) == bool(g["has"][i]) == bool(want.any())
+        a = int(g["action"][i])
+        if a >= 0:
+            rc, nb, nrem = orc.next_state(W, H, N, board, iw, ih, rem, a)
+            assert rc == 0
+            assert np.array_equal(ev.pack_board(nb), g["next_rows"][i, :H]), i
+            assert np.array_equal(nrem, g["next_rem"][i, :N]), i
+
+
+def test_next_state_rejects_placed_item(rules):
+    W, H, N = 4, 3, 2
+    board = np.zeros((H, W), np.uint8)
+    rc, _, _ = orc.next_state(W, H, N, board, [2, 1], [2, 1], [0, 1], 0)
+    assert rc == -1  # BinPackingGame.py:69 assert
+
+
+def test_ranked_reward_matches_reference():
+    d = json.load(open(os.path.join(GOLDEN, "ranked_reward.json")))
+    assert len(d["cases"]) > 800
+    ties = 0
+    for c in d["cases"]:
+        board = ev.unpack_board(np.array(c["rows"], dtype=np.uint64), c["W"])
+        ranked, r = orc.ranked_reward(c["W"], c["H"], board, c["area"], c["max_h"], c["buf"], c["alpha"])
+        assert r == c["r"]
+        assert ranked == c["ranked"]
+        ties += ranked == 2
+    assert ties > 10
+
+
+def test_q_update_state_machine_matches_numpy():
+    d = json.load(open(os.path.join(GOLDEN, "q_update.json")))
+    seen = set()
+    for chain in d["chains"]:
+        q, k = 0.0, 0
+        for n, step in enumerate(chain):
+            q, k = orc.q_update(q, k, n, step["v"], step["v_kind"])
+            assert k == step["q_kind"]
+            assert q == float.fromhex(step["q"]), (chain, n)
+            seen.add((step["v_kind"], k))
+    assert len(seen) >= 6
+
+
+MCTS_FILES = sorted(glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
+
+
+def replay_with_oracle(d):
+    """Plays the fixture's episode with the oracle MCTS (same evaluator, tie rule, move rule)."""
+    W, H, N = int(d["W"]), int(d["H"]), int(d["N"])
+    kind, salt = str(d["kind"]), int(d["salt"])
+    A = W * N
+    m = orc.OracleMCTS(W, H, N, float(d["cpuct"]), float(d["alpha"]),
+                       lambda b, r: ev.table_eval(kind, ev.pack_board(b), r, A, salt),
+                       lambda b, r: ev.tie_value(ev.pack_board(b), r, salt))
+    m.begin_episode(d["item_w"], d["item_h"], int(d["total_area"]), d["buf"])
+    actions, counts, outcome, score = m.play_episode(int(d["sims"]), policy=0)
+    return m, actions, counts, outcome, score
+
+
+@pytest.mark.parametrize("path", MCTS_FILES, ids=[os.path.basename(p)[5:-4] for p in MCTS_FILES])
+def test_mcts_episode_matches_reference(path):
+    d = np.load(path)
+    m, actions, counts, outcome, score = replay_with_oracle(d)
+    assert np.array_equal(actions, d["actions"])
+    assert np.array_equal(counts, d["counts"])
+    assert outcome == int(d["outcome"]) and score == float(d["score"])
+    assert m.evals == int(d["evals"])
+    tree = m.dump()
+    assert len(tree) == len(d["node_es"])
+    e_node = d["e_node"]
+    starts = np.searchsorted(e_node, np.arange(len(d["node_es"]) + 1))
+    for i in range(len(d["node_es"])):
+        rec = tree[(d["node_rows"][i].tobytes(), d["node_rem"][i].tobytes())]
+        assert rec["es"] == int(d["node_es"][i])
+        if rec["es"] != 0:
+            assert rec["es_kind"] == int(d["node_es_kind"][i])
+        assert rec["expanded"] == int(d["node_exp"][i])
+        if rec["expanded"]:
+            assert rec["ns"] == int(d["node_ns"][i])
+            lo, hi = starts[i], starts[i + 1]
+            assert np.array_equal(rec["actions"], d["e_act"][lo:hi])
+            assert np.array_equal(rec["p"], d["e_p"][lo:hi])  # bit-exact float64 priors
+            assert np.array_equal(rec["nsa"], d["e_n"][lo:hi])
+            vis = rec["nsa"] > 0
+            assert np.array_equal(rec["q"][vis], d["e_q"][lo:hi][vis])  # bit-exact Q
+            assert np.array_equal(rec["q_kind"][vis], d["e_qk"][lo:hi][vis])
+    m.close()
+
+
+def test_mcts_fixtures_cover_the_hard_cases():
+    kinds = np.zeros(3, int); strong = 0; n = 0
+    for p in MCTS_FILES:
+        d = np.load(p)
+        kinds += np.bincount(d["e_qk"][d["e_n"] > 0], minlength=3)
+        strong += int((d["node_es_kind"] == 2).sum())
+        n += 1
+    assert n >= 8
+    assert kinds[1] > 0 and strong > 0
