@@ -1,0 +1,203 @@
+/*
+ * rp_engine.h -- C ABI of the MI355X-native self-play bin-packing engine
+ * (librp_engine.so, built from resource_packing_self_play_amd/csrc/rp_engine.hip).
+ *
+ * The reference (Wang-Xiaoyang/resource_packing_self_play) is pure Python and has
+ * no FFI; its boundary for this path is the duck-typed plugin API that
+ * xw_mcts/main_bpp.py:93-121 and xw_mcts/CoachBPP.py drive.  Each entry point
+ * below names the reference method(s) it replaces (paths relative to
+ * /root/reference/xw_mcts).  The Python classes with the reference's names
+ * (resource_packing_self_play_amd.{binpacking.BinPackingGame, MCTS_bpp, CoachBPP,
+ * binpacking.pytorch.NNet}) are thin ctypes callers of this ABI; INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams and device
+ *     buffers cross as void* / raw device pointers).
+ *   - every function returns 0 on success or a negative rp_status; the message is
+ *     available from rp_last_error().  No exception crosses the ABI.
+ *   - the caller owns every buffer it passes; the library owns everything reachable
+ *     from rp_ctx.  Inputs are never modified unless documented as in/out.
+ *   - one rp_ctx per (process, GPU), externally synchronised; all device work is
+ *     enqueued on the stream given at create time.
+ *   - a state is (rows, remaining): rows[r] is the W-bit occupancy of grid row r
+ *     (bit c = cell (r, c)), always passed as uint64; remaining[i] != 0 iff item i is
+ *     still unplaced; item sizes are (w, h) bytes.  action = item * W + column, as
+ *     BinPackingGame.py:67,91.
+ *   - limits: 1 <= W <= 64, 1 <= H <= 64, 1 <= N <= 128.
+ */
+#ifndef RP_ENGINE_H
+#define RP_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_ABI_VERSION 1
+
+typedef enum rp_status {
+    RP_OK = 0,
+    RP_ERR_ARG = -1,        /* bad argument */
+    RP_ERR_DEVICE = -2,     /* HIP error (no GPU, launch failure, ...) */
+    RP_ERR_CAPACITY = -3,   /* a per-game node / edge / table arena overflowed */
+    RP_ERR_ASSERT = -4,     /* a precondition the reference asserts was violated
+                               (BinPackingGame.py:69 item already placed, :89 no legal move) */
+    RP_ERR_STATE = -5       /* call not valid in the engine's current phase */
+} rp_status;
+
+/* how a finished search turns into a move (CoachBPP.py:86-87 draws from OS entropy,
+ * which cannot be reproduced; the engine offers deterministic rules instead) */
+typedef enum rp_move_rule {
+    RP_MOVE_EXTERNAL = 0,   /* host supplies actions through rp_advance_roots */
+    RP_MOVE_ARGMAX_FIRST = 1, /* lowest-index argmax of the root visit counts */
+    RP_MOVE_SAMPLE = 2      /* a ~ counts with a counter-based RNG keyed by (seed, episode id, move) */
+} rp_move_rule;
+
+/* game phases reported by rp_game_status */
+enum { RP_PHASE_IDLE = 0, RP_PHASE_RUNNING = 1, RP_PHASE_WAIT_EVAL = 2, RP_PHASE_MOVE_READY = 3,
+       RP_PHASE_EPISODE_DONE = 4, RP_PHASE_FAILED = 5 };
+
+/* kinds of a stored Q / backed-up value (NumPy promotion state):
+ * 0 weak (Python int/float, f64 arithmetic), 1 float32, 2 strong float64 */
+enum { RP_KIND_WEAK = 0, RP_KIND_F32 = 1, RP_KIND_F64 = 2 };
+
+typedef struct rp_config {
+    int32_t abi_version;   /* RP_ABI_VERSION */
+    int32_t W, H, N;       /* BinPackingGame(bin_width, bin_height, num_items, n) BinPackingGame.py:15 */
+    int32_t games;         /* concurrent game slots G on this GPU */
+    int32_t sims;          /* args.numMCTSSims (MCTS_bpp.py:37) */
+    double cpuct;          /* args.cpuct (MCTS_bpp.py:114,117) */
+    double alpha;          /* args.alpha (MCTS_bpp.py:79) */
+    int32_t node_cap;      /* per-game node arena; 0 = sims * (N + 1) + 2 */
+    int32_t edge_cap;      /* per-game edge arena; 0 = automatic */
+    int32_t move_rule;     /* rp_move_rule */
+    int32_t auto_restart;  /* 1: a finished slot pulls the next instance from the pool set by rp_set_instance_pool */
+    uint64_t seed;         /* RNG seed for RP_MOVE_SAMPLE and the tie rule */
+    uint64_t tie_salt;     /* salt of the deterministic stand-in for np.random.choice([1,-1]) (BinPackingGame.py:212) */
+    int32_t device;        /* HIP device ordinal */
+    int32_t reserved0;
+    void *stream;          /* hipStream_t; NULL = the default stream */
+    int64_t max_examples;  /* capacity of the replay buffer in examples; 0 = none recorded */
+} rp_config;
+
+typedef struct rp_ctx rp_ctx;
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+int rp_version(void);
+/* MCTS.__init__ (MCTS_bpp.py:16-26) + BinPackingGame.__init__ (BinPackingGame.py:15-22) for G games */
+int rp_create(const rp_config *cfg, rp_ctx **out);
+void rp_destroy(rp_ctx *ctx);
+/* message of the last failing call on this ctx (or of rp_create when ctx == NULL) */
+const char *rp_last_error(const rp_ctx *ctx);
+/* bytes of HBM the ctx holds */
+int64_t rp_device_bytes(const rp_ctx *ctx);
+
+/* ---- stateless game rules over a batch of B states (host pointers) -------------------- */
+/* BinPackingGame.getValidMoves (BinPackingGame.py:78-92) -> Bin.get_moves_for_square /
+ * get_adjacency (BinPackingLogic.py:47-93).  mask_out[b][a] in {0,1}; n_valid_out may be NULL.
+ * A state without a legal move yields an all-zero row (the shim raises the reference's
+ * AssertionError of BinPackingGame.py:89). */
+int rp_valid_moves(rp_ctx *ctx, int64_t B, const uint64_t *rows /*[B][H]*/, const uint8_t *remaining /*[B][N]*/,
+                   const uint8_t *item_wh /*[B][N][2]*/, uint8_t *mask_out /*[B][W*N]*/, int32_t *n_valid_out /*[B]*/);
+/* BinPackingGame.getNextState (BinPackingGame.py:58-76) -> Bin.execute_move (BinPackingLogic.py:95-109).
+ * status_out[b] = 0, or RP_ERR_ASSERT when the item is already placed (BinPackingGame.py:69). */
+int rp_apply_move(rp_ctx *ctx, int64_t B, const uint64_t *rows, const uint8_t *remaining, const uint8_t *item_wh,
+                  const int32_t *action /*[B]*/, uint64_t *rows_out, uint8_t *remaining_out, int32_t *status_out);
+/* BinPackingGame.getGameEnded (BinPackingGame.py:109-116) -> has_valid_moves (:94-107) and
+ * getRankedReward (:188-212).  ended_out[b] = 0 (a move exists), +1, -1, or 2 for the r == bl
+ * tie branch (the caller draws); reward_out[b] = r.  rewards is the R2 buffer shared by the batch. */
+int rp_game_ended(rp_ctx *ctx, int64_t B, const uint64_t *rows, const uint8_t *remaining, const uint8_t *item_wh,
+                  const int32_t *total_area /*[B]*/, const int32_t *max_h /*[B]*/, const double *rewards, int32_t n_rewards,
+                  double alpha, int32_t *ended_out, double *reward_out);
+
+/* ---- episode set-up ------------------------------------------------------------------ */
+/* Items of game slot(s): BinPackingGame.getInitItems (BinPackingGame.py:37-51, also fixes max_h)
+ * and CoachBPP.items_total_area (CoachBPP.py:34,119).  Starts a new episode for slots
+ * first..first+count-1 at the empty board with an empty tree (CoachBPP.py:67-68,124). */
+int rp_begin_episodes(rp_ctx *ctx, int32_t first, int32_t count, const uint8_t *item_wh /*[count][N][2]*/,
+                      const int32_t *total_area /*[count]*/, const uint64_t *episode_id /*[count] or NULL*/);
+/* Pool of instances for auto_restart: slot g takes instance g at rp_begin_pool and a finished
+ * slot takes the next unused one; episode id = pool index + first_id. */
+int rp_set_instance_pool(rp_ctx *ctx, int64_t n_instances, const uint8_t *item_wh /*[n][N][2]*/,
+                         const int32_t *total_area /*[n]*/, uint64_t first_id);
+int rp_begin_pool(rp_ctx *ctx);
+/* R2 buffer snapshot (rewards_list argument of MCTS.getActionProb / getGameEnded, CoachBPP.py:76-91):
+ * the threshold sorted[int(floor(len*alpha))-1] is recomputed and used by every slot from now on. */
+int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n);
+/* Re-root slot(s) at an arbitrary state without clearing the tree (MCTS.getActionProb called with a
+ * new canonicalBoard on the same MCTS object, CoachBPP.py:74-78). */
+int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uint64_t *rows /*[count][H]*/,
+                 const uint8_t *remaining /*[count][N]*/);
+
+/* ---- search: MCTS.search (MCTS_bpp.py:56-139) in lock step over all slots ------------- */
+/* Runs simulations for every RUNNING slot until each either needs a leaf evaluated (the
+ * nnet.predict call of MCTS_bpp.py:87) or has finished its args.numMCTSSims budget
+ * (select :106-121, descend :125-128, terminal :78-83, backup :130-139 on device).
+ * Enqueues work only; *n_leaves_out (may be NULL) forces a stream sync and returns the number of
+ * leaves waiting for evaluation. */
+int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out);
+/* Writes the evaluator input of the waiting leaves, FP32 NCHW [n][N+1][H][W] exactly as
+ * BinPackingGame.getBinItem + NNet.predict's view (BinPackingGame.py:118-120, NNet.py:77-79),
+ * into caller-owned DEVICE memory (capacity_rows rows). */
+int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows);
+/* Host copy of the waiting leaves' packed states and slots (parity tests, host evaluators). */
+int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out /*[n][H]*/, uint8_t *remaining_out /*[n][N]*/,
+                   int32_t *slot_out /*[n]*/, int32_t *n_out);
+/* Expansion + backup: masks and renormalises pi with the leaf's valid moves (MCTS_bpp.py:88-100,
+ * float64, NumPy summation order), stores Vs/Ns (:102-103) and backs v up the path (:130-139).
+ * pi_dev [n][W*N] and v_dev [n] are DEVICE float32 (probabilities, i.e. exp(log_softmax), NNet.py:85),
+ * row b belonging to the b-th waiting leaf. */
+int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev);
+/* Same with HOST float32 buffers (tests, CPU evaluators). */
+int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows);
+
+/* ---- results ------------------------------------------------------------------------- */
+/* counts[a] = Nsa[(root, a)] (MCTS_bpp.py:40-41), host buffer [count][W*N] */
+int rp_root_counts(rp_ctx *ctx, int32_t first, int32_t count, uint32_t *counts_out);
+/* phase_out / sims_done_out / moves_out / episode_out: host buffers [count] (any may be NULL) */
+int rp_game_status(rp_ctx *ctx, int32_t first, int32_t count, int32_t *phase_out, int32_t *sims_done_out,
+                   int32_t *moves_out, uint64_t *episode_out);
+/* Plays `action[i]` in slot first+i (CoachBPP.py:88-91): the child becomes the root, the tree is
+ * kept; ended_out[i] = 0 / +-1 as getGameEnded, score_out[i] = r.  Only with RP_MOVE_EXTERNAL. */
+int rp_advance_roots(rp_ctx *ctx, int32_t first, int32_t count, const int32_t *action, int32_t *ended_out,
+                     double *score_out);
+/* Finished episodes since the last call (auto move rules): up to max_n records, oldest first. */
+int rp_pop_finished(rp_ctx *ctx, int64_t max_n, uint64_t *episode_id_out, int32_t *outcome_out, double *score_out,
+                    int32_t *moves_out, int64_t *n_out);
+/* Engine counters summed over slots since create/reset: [0] simulations, [1] expansions (leaf evaluations),
+ * [2] terminal returns, [3] path edges walked, [4] sum of n_valid at selected nodes, [5] sum of n_valid at
+ * expanded leaves, [6] transposition links, [7] nodes created, [8] moves played, [9] episodes finished,
+ * [10] hash probes (64-slot windows), [11] key bytes compared. */
+int rp_counters(rp_ctx *ctx, int64_t *out12, int32_t reset);
+
+/* ---- replay buffer (CoachBPP.executeEpisode's trainExamples, CoachBPP.py:80,99) -------- */
+/* Number of examples recorded so far. */
+int rp_examples_count(rp_ctx *ctx, int64_t *n_out);
+/* Dense training tensors for examples [first, first+count): planes FP32 [count][N+1][H][W],
+ * pi FP32 [count][W*N] (= counts / sum, MCTS_bpp.py:51-54), value FP32 [count] (the episode's ranked
+ * outcome, 0 while the episode is unfinished) -- DEVICE buffers. */
+int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes_dev, float *pi_dev, float *value_dev);
+int rp_examples_clear(rp_ctx *ctx);
+
+/* ---- inspection (parity tests) --------------------------------------------------------- */
+/* Sizes of slot g's tree: nodes and edges in use. */
+int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out);
+/* Host copy of slot g's tree.  Node i: rows u64[H], remaining u8[N], term i8 (0 / +-1 = Es),
+ * term_kind u8, expanded u8, ns u32, edge_off u32, n_valid u32.  Edge e: action u16, P f64, Q f64,
+ * nsa u32, q_kind u8, child u32 (0xFFFFFFFF = not linked yet). */
+int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint8_t *node_remaining, int8_t *node_term,
+                 uint8_t *node_term_kind, uint8_t *node_expanded, uint32_t *node_ns, uint32_t *node_edge_off,
+                 uint32_t *node_n_valid, uint16_t *edge_action, double *edge_p, double *edge_q, uint32_t *edge_nsa,
+                 uint8_t *edge_q_kind, uint32_t *edge_child);
+/* Device self-tests used by the GPU parity suite: sqrt / Q-update / NumPy-order sum on device,
+ * host buffers in and out. */
+int rp_selftest_sqrt(rp_ctx *ctx, int64_t n, double *sqrt_n_out, double *sqrt_n_eps_out);
+int rp_selftest_q_update(rp_ctx *ctx, int64_t n, const double *q, const uint8_t *q_kind, const uint32_t *nsa,
+                         const double *v, const uint8_t *v_kind, double *q_out, uint8_t *q_kind_out);
+int rp_selftest_masked_prior(rp_ctx *ctx, int64_t B, const float *pi /*[B][A]*/, const uint8_t *valid /*[B][A]*/,
+                             double *p_out /*[B][A]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -372,12 +372,12 @@ void orc_mcts_begin_episode(orc_mcts *m, const uint8_t *item_w, const uint8_t *i
 typedef struct { double v; int kind; } val_t;
 
 /* MCTS.search (MCTS_bpp.py:56-139). key = board cells + remaining flags. */
-static val_t search(orc_mcts *m, const uint8_t *key, int came_by_edge) {
+static val_t search(orc_mcts *m, const uint8_t *key, int first_traversal) {
     const int W = m->W, H = m->H, N = m->N, A = m->A;
     const uint8_t *board = key, *remaining = key + W * H;
     int created = 0;
     node *nd = lookup(m, key, 1, &created); /* s = stringRepresentation(...) (:76) */
-    if (!created && came_by_edge) m->stats[6]++;
+    if (!created && first_traversal) m->stats[6]++; /* an edge led to a state another path had created */
     if (!nd->has_es) { /* :78-79 */
         double r;
         int e = orc_game_ended(W, H, N, board, m->item_w, m->item_h, remaining, m->total_area, m->max_h, m->rewards,
@@ -442,7 +442,7 @@ static val_t search(orc_mcts *m, const uint8_t *key, int came_by_edge) {
     uint8_t *next = (uint8_t *)malloc((size_t)m->keylen); /* :125-126 */
     memcpy(next, key, (size_t)m->keylen);
     orc_next_state(W, H, N, next, m->item_w, m->item_h, next + W * H, a);
-    val_t v = search(m, next, 1); /* :128 */
+    val_t v = search(m, next, nd->nsa[a] == 0 ? 1 : 0); /* :128; flag = first traversal of this edge (stats only) */
     free(next);
     int qk = nd->q_kind[a];
     orc_q_update(&nd->q[a], &qk, nd->nsa[a], v.v, v.kind); /* :130-136 */

@@ -1,0 +1,294 @@
+"""ctypes binding of librp_engine.so (include/rp_engine.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible,
+constructing an engine raises.  Build with `python __graft_entry__.py build` or
+`make -C resource_packing_self_play_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "librp_engine.so")
+ABI_VERSION = 1
+
+MOVE_EXTERNAL, MOVE_ARGMAX_FIRST, MOVE_SAMPLE = 0, 1, 2
+PHASE_IDLE, PHASE_RUNNING, PHASE_WAIT_EVAL, PHASE_MOVE_READY, PHASE_EPISODE_DONE, PHASE_FAILED = range(6)
+KIND_WEAK, KIND_F32, KIND_F64 = 0, 1, 2
+ERR_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_ASSERT, ERR_STATE = -1, -2, -3, -4, -5
+COUNTER_NAMES = ("simulations", "expansions", "terminal_returns", "path_edges", "sum_valid_select", "sum_valid_leaf",
+                 "transposition_links", "nodes", "moves", "episodes", "hash_probes", "key_bytes")
+
+
+class RpConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("games", C.c_int32),
+                ("sims", C.c_int32), ("cpuct", C.c_double), ("alpha", C.c_double), ("node_cap", C.c_int32),
+                ("edge_cap", C.c_int32), ("move_rule", C.c_int32), ("auto_restart", C.c_int32), ("seed", C.c_uint64),
+                ("tie_salt", C.c_uint64), ("device", C.c_int32), ("reserved0", C.c_int32), ("stream", C.c_void_p),
+                ("max_examples", C.c_int64)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rp_engine error %d: %s" % (code, msg))
+        self.code = code
+
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_SIGS = {
+    "rp_version": (C.c_int, []),
+    "rp_create": (C.c_int, [C.POINTER(RpConfig), C.POINTER(_vp)]),
+    "rp_destroy": (None, [_vp]),
+    "rp_last_error": (C.c_char_p, [_vp]),
+    "rp_device_bytes": (_i64, [_vp]),
+    "rp_valid_moves": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "rp_apply_move": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rp_game_ended": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp]),
+    "rp_begin_episodes": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "rp_set_instance_pool": (C.c_int, [_vp, _i64, _vp, _vp, C.c_uint64]),
+    "rp_begin_pool": (C.c_int, [_vp]),
+    "rp_set_rank_buffer": (C.c_int, [_vp, _vp, _i32]),
+    "rp_set_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "rp_search_step": (C.c_int, [_vp, _vp]),
+    "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
+    "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "rp_commit_eval": (C.c_int, [_vp, _vp, _vp]),
+    "rp_commit_eval_host": (C.c_int, [_vp, _vp, _vp, _i32]),
+    "rp_root_counts": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "rp_game_status": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "rp_advance_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "rp_pop_finished": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "rp_counters": (C.c_int, [_vp, _vp, _i32]),
+    "rp_examples_count": (C.c_int, [_vp, _vp]),
+    "rp_examples_tensors": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "rp_examples_clear": (C.c_int, [_vp]),
+    "rp_tree_size": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "rp_dump_tree": (C.c_int, [_vp, _i32] + [_vp] * 14),
+    "rp_selftest_sqrt": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rp_selftest_q_update": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rp_selftest_masked_prior": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+}
+_lib = None
+
+
+def load():
+    """Loads the shared library and checks the ABI version.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build the HIP engine first (python __graft_entry__.py build); "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.rp_version() != ABI_VERSION:
+            raise ImportError("librp_engine.so ABI %d != %d" % (L.rp_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+class Engine:
+    """Thin object wrapper of one rp_ctx (one per process and GPU)."""
+
+    def __init__(self, W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=MOVE_EXTERNAL, seed=0, tie_salt=0,
+                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0):
+        self.L = load()
+        self.W, self.H, self.N, self.A, self.G, self.sims = int(W), int(H), int(N), int(W) * int(N), int(games), int(sims)
+        cfg = RpConfig(ABI_VERSION, W, H, N, games, sims, float(cpuct), float(alpha), node_cap, edge_cap, move_rule,
+                       auto_restart, seed, tie_salt, device, 0, stream or None, max_examples)
+        h = _vp()
+        rc = self.L.rp_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self.L.rp_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.rp_last_error(self.h).decode())
+
+    @property
+    def device_bytes(self):
+        return self.L.rp_device_bytes(self.h)
+
+    # ---- stateless rules -----------------------------------------------------------------
+    def valid_moves(self, rows, remaining, item_wh):
+        rows = _arr(rows, np.uint64); B = rows.shape[0]
+        rows = _arr(rows, np.uint64, (B, self.H)); remaining = _arr(remaining, np.uint8, (B, self.N))
+        item_wh = _arr(item_wh, np.uint8, (B, self.N, 2))
+        mask = np.empty((B, self.A), np.uint8); nv = np.empty(B, np.int32)
+        self._ck(self.L.rp_valid_moves(self.h, B, _ptr(rows), _ptr(remaining), _ptr(item_wh), _ptr(mask), _ptr(nv)))
+        return mask, nv
+
+    def apply_move(self, rows, remaining, item_wh, action):
+        rows = _arr(rows, np.uint64); B = rows.shape[0]
+        rows = _arr(rows, np.uint64, (B, self.H)); remaining = _arr(remaining, np.uint8, (B, self.N))
+        item_wh = _arr(item_wh, np.uint8, (B, self.N, 2)); action = _arr(action, np.int32, (B,))
+        rows_o = np.empty_like(rows); rem_o = np.empty_like(remaining); st = np.empty(B, np.int32)
+        self._ck(self.L.rp_apply_move(self.h, B, _ptr(rows), _ptr(remaining), _ptr(item_wh), _ptr(action), _ptr(rows_o), _ptr(rem_o), _ptr(st)))
+        return rows_o, rem_o, st
+
+    def game_ended(self, rows, remaining, item_wh, total_area, max_h, rewards, alpha):
+        rows = _arr(rows, np.uint64); B = rows.shape[0]
+        rows = _arr(rows, np.uint64, (B, self.H)); remaining = _arr(remaining, np.uint8, (B, self.N))
+        item_wh = _arr(item_wh, np.uint8, (B, self.N, 2))
+        total_area = _arr(total_area, np.int32, (B,)); max_h = _arr(max_h, np.int32, (B,))
+        rewards = _arr(rewards, np.float64)
+        ended = np.empty(B, np.int32); r = np.empty(B, np.float64)
+        self._ck(self.L.rp_game_ended(self.h, B, _ptr(rows), _ptr(remaining), _ptr(item_wh), _ptr(total_area), _ptr(max_h),
+                                      _ptr(rewards) if rewards.size else None, rewards.size, float(alpha), _ptr(ended), _ptr(r)))
+        return ended, r
+
+    # ---- episodes ------------------------------------------------------------------------
+    def set_rank_buffer(self, rewards):
+        rewards = _arr(rewards, np.float64)
+        self._ck(self.L.rp_set_rank_buffer(self.h, _ptr(rewards) if rewards.size else None, rewards.size))
+
+    def begin_episodes(self, item_wh, total_area, first=0, episode_id=None):
+        item_wh = _arr(item_wh, np.uint8); count = item_wh.shape[0]
+        item_wh = _arr(item_wh, np.uint8, (count, self.N, 2)); total_area = _arr(total_area, np.int32, (count,))
+        ids = None if episode_id is None else _arr(episode_id, np.uint64, (count,))
+        self._ck(self.L.rp_begin_episodes(self.h, first, count, _ptr(item_wh), _ptr(total_area), _ptr(ids)))
+
+    def set_roots(self, rows, remaining, first=0):
+        rows = _arr(rows, np.uint64); count = rows.shape[0]
+        rows = _arr(rows, np.uint64, (count, self.H)); remaining = _arr(remaining, np.uint8, (count, self.N))
+        self._ck(self.L.rp_set_roots(self.h, first, count, _ptr(rows), _ptr(remaining)))
+
+    # ---- search --------------------------------------------------------------------------
+    def search_step(self, sync=True):
+        if not sync:
+            self._ck(self.L.rp_search_step(self.h, None))
+            return None
+        n = _i32(0)
+        self._ck(self.L.rp_search_step(self.h, C.byref(n)))
+        return n.value
+
+    def leaf_planes(self, dev_ptr, capacity_rows):
+        self._ck(self.L.rp_leaf_planes(self.h, C.c_void_p(dev_ptr), capacity_rows))
+
+    def leaf_states(self, max_rows=None):
+        max_rows = self.G if max_rows is None else max_rows
+        rows = np.empty((max_rows, self.H), np.uint64); rem = np.empty((max_rows, self.N), np.uint8)
+        slot = np.empty(max_rows, np.int32); n = _i32(0)
+        self._ck(self.L.rp_leaf_states(self.h, max_rows, _ptr(rows), _ptr(rem), _ptr(slot), C.byref(n)))
+        return rows[:n.value], rem[:n.value], slot[:n.value]
+
+    def commit_eval(self, pi_dev_ptr, v_dev_ptr):
+        self._ck(self.L.rp_commit_eval(self.h, C.c_void_p(pi_dev_ptr), C.c_void_p(v_dev_ptr)))
+
+    def commit_eval_host(self, pi, v):
+        pi = _arr(pi, np.float32); n = pi.shape[0]
+        pi = _arr(pi, np.float32, (n, self.A)); v = _arr(v, np.float32).reshape(-1)
+        if v.shape[0] != n:
+            raise ValueError("v must have one entry per pi row")
+        self._ck(self.L.rp_commit_eval_host(self.h, _ptr(pi), _ptr(v), n))
+
+    def run_host(self, evaluate, max_steps=10 ** 9):
+        """Runs search steps with a HOST evaluator `evaluate(rows[n,H], rem[n,N]) -> (pi[n,A], v[n])` until no
+        slot waits for an evaluation (all slots MOVE_READY / done).  Test and plumbing path."""
+        steps = 0
+        while steps < max_steps:
+            n = self.search_step()
+            if n == 0:
+                return steps
+            rows, rem, _ = self.leaf_states(n)
+            pi, v = evaluate(rows, rem)
+            self.commit_eval_host(pi, v)
+            steps += 1
+        return steps
+
+    # ---- results -------------------------------------------------------------------------
+    def root_counts(self, first=0, count=None):
+        count = self.G - first if count is None else count
+        out = np.empty((count, self.A), np.uint32)
+        self._ck(self.L.rp_root_counts(self.h, first, count, _ptr(out)))
+        return out
+
+    def status(self, first=0, count=None):
+        count = self.G - first if count is None else count
+        ph = np.empty(count, np.int32); sd = np.empty(count, np.int32); mv = np.empty(count, np.int32); ep = np.empty(count, np.uint64)
+        self._ck(self.L.rp_game_status(self.h, first, count, _ptr(ph), _ptr(sd), _ptr(mv), _ptr(ep)))
+        return ph, sd, mv, ep
+
+    def advance_roots(self, action, first=0):
+        action = _arr(action, np.int32).reshape(-1); count = action.shape[0]
+        ended = np.empty(count, np.int32); score = np.empty(count, np.float64)
+        self._ck(self.L.rp_advance_roots(self.h, first, count, _ptr(action), _ptr(ended), _ptr(score)))
+        return ended, score
+
+    def pop_finished(self, max_n=1 << 20):
+        ids = np.empty(max_n, np.uint64); oc = np.empty(max_n, np.int32); sc = np.empty(max_n, np.float64); mv = np.empty(max_n, np.int32)
+        n = _i64(0)
+        self._ck(self.L.rp_pop_finished(self.h, max_n, _ptr(ids), _ptr(oc), _ptr(sc), _ptr(mv), C.byref(n)))
+        k = n.value
+        return ids[:k], oc[:k], sc[:k], mv[:k]
+
+    def counters(self, reset=False):
+        out = np.zeros(12, np.int64)
+        self._ck(self.L.rp_counters(self.h, _ptr(out), 1 if reset else 0))
+        return dict(zip(COUNTER_NAMES, out.tolist()))
+
+    def tree_size(self, slot):
+        a, b = _i32(0), _i32(0)
+        self._ck(self.L.rp_tree_size(self.h, slot, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def dump_tree(self, slot):
+        nn, ne = self.tree_size(slot)
+        d = dict(node_rows=np.zeros((nn, self.H), np.uint64), node_rem=np.zeros((nn, self.N), np.uint8), node_term=np.zeros(nn, np.int8),
+                 node_term_kind=np.zeros(nn, np.uint8), node_expanded=np.zeros(nn, np.uint8), node_ns=np.zeros(nn, np.uint32),
+                 node_edge_off=np.zeros(nn, np.uint32), node_n_valid=np.zeros(nn, np.uint32), edge_action=np.zeros(ne, np.uint16),
+                 edge_p=np.zeros(ne, np.float64), edge_q=np.zeros(ne, np.float64), edge_nsa=np.zeros(ne, np.uint32),
+                 edge_q_kind=np.zeros(ne, np.uint8), edge_child=np.zeros(ne, np.uint32))
+        self._ck(self.L.rp_dump_tree(self.h, slot, *[_ptr(d[k]) for k in (
+            "node_rows", "node_rem", "node_term", "node_term_kind", "node_expanded", "node_ns", "node_edge_off", "node_n_valid",
+            "edge_action", "edge_p", "edge_q", "edge_nsa", "edge_q_kind", "edge_child")]))
+        return d
+
+    # ---- self tests ----------------------------------------------------------------------
+    def selftest_sqrt(self, n):
+        a = np.empty(n, np.float64); b = np.empty(n, np.float64)
+        self._ck(self.L.rp_selftest_sqrt(self.h, n, _ptr(a), _ptr(b)))
+        return a, b
+
+    def selftest_q_update(self, q, q_kind, nsa, v, v_kind):
+        q = _arr(q, np.float64); n = q.shape[0]
+        q_kind = _arr(q_kind, np.uint8, (n,)); nsa = _arr(nsa, np.uint32, (n,)); v = _arr(v, np.float64, (n,)); v_kind = _arr(v_kind, np.uint8, (n,))
+        qo = np.empty(n, np.float64); ko = np.empty(n, np.uint8)
+        self._ck(self.L.rp_selftest_q_update(self.h, n, _ptr(q), _ptr(q_kind), _ptr(nsa), _ptr(v), _ptr(v_kind), _ptr(qo), _ptr(ko)))
+        return qo, ko
+
+    def selftest_masked_prior(self, pi, valid):
+        pi = _arr(pi, np.float32); B = pi.shape[0]
+        pi = _arr(pi, np.float32, (B, self.A)); valid = _arr(valid, np.uint8, (B, self.A))
+        out = np.empty((B, self.A), np.float64)
+        self._ck(self.L.rp_selftest_masked_prior(self.h, B, _ptr(pi), _ptr(valid), _ptr(out)))
+        return out

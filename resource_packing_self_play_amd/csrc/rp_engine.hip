@@ -1,0 +1,1697 @@
+// rp_engine.hip -- MI355X (gfx950 / CDNA4) self-play bin-packing engine: game rules, the
+// transposition-DAG Monte-Carlo tree search and the evaluator plumbing, behind the C ABI of
+// include/rp_engine.h.
+//
+// Execution model: one 64-lane wavefront owns one game slot.  A grid row lives in the lane with the
+// same index (rows are W-bit masks, W <= 64, H <= 64), so the reference's per-cell Python loops
+// (BinPackingLogic.py:47-109) become popcounts, ballots and readlanes over a register-resident
+// board.  Every tree of a slot is a structure of arrays in HBM: 16-byte node headers, bit-packed
+// node keys (the state), and per-node CONTIGUOUS edge runs (valid moves only) in separate
+// P / Q / N / child / action arrays so a wave reads a node's edges as coalesced 64-lane loads.
+// Transpositions (the reference keys its dicts by the full state, MCTS_bpp.py:20-26,76) go through a
+// per-slot open-addressing table probed 64 slots per wave instruction.
+//
+// Numerics: compiled with -ffp-contract=off; the PUCT score is float64, Q follows the NumPy promotion
+// state machine of the reference's backup expression, the prior is renormalised in NumPy's pairwise
+// summation order.  See DESIGN.md.
+//
+// Reference paths cited below are relative to /root/reference/xw_mcts.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/rp_engine.h"
+
+#pragma clang fp contract(off)
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+#define NONE32 0xFFFFFFFFu
+#define NSA_MASK 0x3FFFFFFFu
+#define WAVES_PER_BLOCK 4
+#define MAX_LEAVES 128
+#define MAX_MASK_WORDS 256 /* A <= 8192 */
+
+enum { CNT_SIMS = 0, CNT_EXPAND, CNT_TERMINAL, CNT_PATH, CNT_NVALID_SEL, CNT_NVALID_LEAF, CNT_TRANSPOSE, CNT_NODES,
+       CNT_MOVES, CNT_EPISODES, CNT_PROBES, CNT_KEYBYTES, CNT_N };
+enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7 };
+
+struct NodeHdr {   // 16 bytes, one dwordx4 load per visited node
+    u32 ns;        // Ns[s]          (MCTS_bpp.py:103,138)
+    u32 edge_off;  // first edge of this node in the slot's edge arrays
+    u32 n_valid;   // number of valid moves = edges (Vs[s], :102)
+    int8_t term;   // Es[s]: 0 not ended, +1 / -1 ranked outcome (:78-83)
+    u8 term_kind;  // RP_KIND_WEAK (Python int) or RP_KIND_F64 (np.int64 from the tie branch)
+    u8 expanded;   // s in Ps
+    u8 pad;
+};
+
+struct DP {  // device view of a context, passed by value to every kernel
+    int W, H, N, A, G, sims, node_cap, edge_cap, table_cap, KW, RW, RMW, move_rule;
+    u32 magicW;  // a / W == (a * magicW) >> 20 for a < 8192
+    double cpuct;
+    u64 seed, tie_salt;
+    // per slot
+    u8 *item_wh;  // [G][N][2]
+    int *total_area, *max_h;
+    double *bl;     // R2 threshold snapshot taken when the episode began
+    int *has_buf;
+    u32 *root, *n_nodes, *n_edges;
+    int *phase, *sims_done, *moves;
+    u64 *episode;
+    u32 *leaf_node;
+    int *path_len;
+    u32 *path_edge, *path_node;  // [G][N]
+    int *game_row;
+    int *last_outcome;
+    double *last_score;
+    // evaluation queue
+    int *eval_count, *eval_slot;
+    // arenas
+    NodeHdr *hdr;   // [G][node_cap]
+    u32 *key;       // [G][node_cap][KW]
+    double *eP, *eQ;  // [G][edge_cap]
+    u32 *eN, *eChild;
+    u16 *eAct;
+    u64 *table;     // [G][table_cap]  (tag << 32) | (node id + 1), 0 = empty
+    // NumPy pairwise-sum plan over A elements
+    int n_leaves;
+    const int *leaf_lo, *leaf_n, *sched_dst, *sched_src;
+    // global
+    double *g_bl;
+    int *g_has_buf;
+    u64 *counters;
+    int *error;
+    // instance pool for auto_restart
+    int auto_restart;
+    long long n_instances;
+    u64 first_id;
+    const u8 *pool_wh;      // [n_instances][N][2]
+    const int *pool_area, *pool_max_h;
+    unsigned long long *next_instance;
+    // replay buffer (CoachBPP.executeEpisode's trainExamples, CoachBPP.py:80,99)
+    long long max_examples;
+    unsigned long long *ex_count;
+    u32 *ex_key;      // [max_examples][KW]
+    u8 *ex_wh;        // [max_examples][N][2]
+    u32 *ex_counts;   // [max_examples][A]  root visit counts
+    int *ex_value;    // ranked outcome of the episode, 0 until it ends
+    u32 *slot_ex;     // [G][N] example indices of the running episode
+    // finished-episode ring
+    int fin_cap;
+    int *fin_count;
+    u64 *fin_episode;
+    int *fin_outcome, *fin_moves;
+    double *fin_score;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ void wave_sync() {
+    // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
+    // memory operations across the point and makes earlier stores visible to the other lanes.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ u64 lanes_below() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ u64 wave_xor_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v ^= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 mix64(u64 x) {  // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline u64 full_mask(int w) { return w >= 64 ? ~0ull : ((1ull << w) - 1ull); }
+
+template <typename row_t> struct RowOps;
+template <> struct RowOps<u32> {
+    static __device__ __forceinline__ u32 at(u32 mine, int r) { return (u32)__builtin_amdgcn_readlane((int)mine, r); }
+    static __device__ __forceinline__ int popc(u32 x) { return __popc(x); }
+};
+template <> struct RowOps<u64> {
+    static __device__ __forceinline__ u64 at(u64 mine, int r) {
+        u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)mine, r);
+        u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(mine >> 32), r);
+        return ((u64)hi << 32) | lo;
+    }
+    static __device__ __forceinline__ int popc(u64 x) { return __popcll(x); }
+};
+
+// bits j .. j+w-1, clipped at W exactly like the NumPy slice board[r, j:j+w]
+template <typename row_t> __device__ __forceinline__ row_t window(int j, int w, int W) {
+    return (row_t)((full_mask(w) << j) & full_mask(W));
+}
+
+// ------------------------------------------------------------------------------------------------
+// game rules on the register-resident board
+// ------------------------------------------------------------------------------------------------
+// Bin.get_moves_for_square + Bin.get_adjacency for ONE (item, column) per lane
+// (BinPackingLogic.py:80-93 and :47-78).  Must be called by all 64 lanes (it shuffles).
+//   legal  <=>  sum(board[:, j:j+w]) <= w*H - w*h                       (:89, a CELL count)
+//          and  (j == 0  or  board[t, j-1] > 0)                          (:63-70)
+//               with t = first row whose window is empty, H-1 if none   (:66-68 for/break fall-through)
+template <typename row_t>
+__device__ __forceinline__ bool move_is_legal(row_t myrow, int H, int W, int j, int w, int h) {
+    const row_t M = window<row_t>(j, w, W);
+    int occupied = 0, t = -1;
+    for (int r = 0; r < H; ++r) {
+        row_t x = RowOps<row_t>::at(myrow, r) & M;
+        occupied += RowOps<row_t>::popc(x);
+        if (t < 0 && x == 0) t = r;
+    }
+    if (t < 0) t = H - 1;
+    row_t trow = __shfl(myrow, t);
+    bool adjacent = (j == 0) || ((trow >> (j > 0 ? j - 1 : 0)) & 1);
+    return (occupied <= w * H - w * h) && adjacent;
+}
+
+struct ValidSink {  // where gen_valid_moves puts its result
+    u16 *act;       // edge action array (or null)
+    double *eP, *eQ;
+    u32 *eN, *eChild;
+    u8 *mask;       // dense 0/1 mask of A bytes (or null)
+    int cap;        // edges available
+};
+
+// BinPackingGame.getValidMoves (BinPackingGame.py:78-92): lanes stride the action space a = item*W + j,
+// legal moves are compacted in ascending action order with ballot + prefix popcount.
+// Returns the number of legal moves, or -1 if they do not fit sink.cap.
+template <typename row_t>
+__device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u64 rem1, const ValidSink &sink) {
+    const int lane = lane_id();
+    int nv = 0;
+    for (int base = 0; base < p.A; base += 64) {
+        int a = base + lane;
+        bool act = a < p.A;
+        int i = act ? (int)(((u32)a * p.magicW) >> 20) : 0;
+        int j = a - i * p.W;
+        bool unplaced = ((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull) != 0;  // plane sum != 0 (:86)
+        act = act && unplaced;
+        int w = 1, h = 1;
+        if (act) { w = wh[2 * i]; h = wh[2 * i + 1]; }
+        act = act && (j <= p.W - w);  // for j in range(W - w + 1) (BinPackingLogic.py:87)
+        if (__ballot(act) == 0ull) {
+            if (sink.mask && a < p.A) sink.mask[a] = 0;
+            continue;
+        }
+        if (!act) { j = 0; w = 1; h = 1; }
+        bool ok = move_is_legal<row_t>(myrow, p.H, p.W, j, w, h) && act;
+        u64 m = __ballot(ok);
+        int cnt = __popcll(m);
+        if (sink.mask && a < p.A) sink.mask[a] = ok ? 1 : 0;
+        if (sink.act) {
+            if (nv + cnt > sink.cap) return -1;
+            if (ok) {
+                int e = nv + __popcll(m & lanes_below());
+                sink.act[e] = (u16)a;
+                sink.eP[e] = 0.0;
+                sink.eQ[e] = 0.0;
+                sink.eN[e] = 0u;
+                sink.eChild[e] = NONE32;
+            }
+        }
+        nv += cnt;
+    }
+    return nv;
+}
+
+// Bin.execute_move (BinPackingLogic.py:95-109): rows are scanned bottom-up (row 0 first), every row
+// whose window is empty gets the window filled until h rows are filled.  Lane r owns row r: the
+// ballot of "window empty" marks the candidate rows, the first h of them (prefix popcount) fill.
+template <typename row_t>
+__device__ __forceinline__ row_t apply_move_rows(row_t myrow, int H, int W, int j, int w, int h) {
+    const row_t M = window<row_t>(j, w, W);
+    bool empty = (lane_id() < H) && ((myrow & M) == 0);
+    u64 m = __ballot(empty);
+    if (empty && __popcll(m & lanes_below()) < h) myrow |= M;
+    return myrow;
+}
+
+// BinPackingGame.getRankedReward (BinPackingGame.py:188-212) + get_minimal_bin_height (:181-186).
+// Returns +1 / -1 or 2 for the r == bl tie; *r_out = r.
+template <typename row_t>
+__device__ int ranked_reward(row_t myrow, int H, int W, int total_area, int max_h, bool has_buf, double bl, double *r_out) {
+    int cells = wave_sum_i32(lane_id() < H ? RowOps<row_t>::popc(myrow) : 0);
+    u64 occ = __ballot(lane_id() < H && myrow != 0);
+    int top = occ ? 64 - __clzll(occ) : 1;  // 1 + highest occupied row; 1 on an empty grid
+    double r;
+    if (cells != total_area) {
+        r = 0.0;  // :193-195
+    } else {
+        double need = ceil((double)total_area / (double)W);  // np.ceil(area / W)
+        double best = need >= (double)max_h ? need : (double)max_h;
+        r = best / (double)top;  // :198
+    }
+    *r_out = r;
+    if (!has_buf) return 1;            // :203-204
+    if (r > bl || r == 1.0) return 1;  // :207-208
+    if (r < bl) return -1;             // :209-210
+    return 2;                          // :211-212
+}
+
+// deterministic stand-in for np.random.choice([1,-1]) (BinPackingGame.py:212): sequential splitmix64 over
+// the row masks and the remaining-item words (tests/evaluators.py tie_value computes the same).
+template <typename row_t>
+__device__ int tie_value(row_t myrow, int H, int N, u64 rem0, u64 rem1, u64 salt) {
+    u64 h = mix64(salt);
+    for (int r = 0; r < H; ++r) h = mix64(h ^ (u64)RowOps<row_t>::at(myrow, r));
+    h = mix64(h ^ rem0);
+    if (N > 64) h = mix64(h ^ rem1);
+    return (mix64(h ^ 0x7469ull) & 1ull) ? 1 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q update: (Nsa*Qsa + v)/(Nsa+1) of MCTS_bpp.py:131 under NumPy 2 promotion (see oracle/rp_oracle.c
+// orc_q_update for the derivation).  Q is stored as a double plus a 2-bit kind.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void q_update(double &q, u32 &kind, u32 n, double v, u32 vkind) {
+    if (n == 0) { q = v; kind = vkind; return; }  // :135
+    const double dn = (double)n, dn1 = (double)(n + 1);
+    if (kind == RP_KIND_WEAK) {
+        double nq = dn * q;
+        if (vkind == RP_KIND_F32) {
+            float s = (float)nq + (float)v;
+            q = (double)(s / (float)dn1);
+            kind = RP_KIND_F32;
+        } else {
+            q = (nq + v) / dn1;
+            kind = vkind;
+        }
+    } else if (kind == RP_KIND_F32) {
+        float nq = (float)dn * (float)q;
+        if (vkind == RP_KIND_F64) {
+            q = ((double)nq + v) / dn1;
+            kind = RP_KIND_F64;
+        } else {
+            float s = nq + (float)v;
+            q = (double)(s / (float)dn1);
+        }
+    } else {
+        q = (dn * q + v) / dn1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// slot-local tree
+// ------------------------------------------------------------------------------------------------
+template <typename row_t> struct Tree {
+    const DP &p;
+    int g;
+    NodeHdr *hdr;
+    u32 *key;
+    double *eP, *eQ;
+    u32 *eN, *eChild;
+    u16 *eAct;
+    u64 *table;
+    const u8 *wh;
+    u32 n_nodes, n_edges;
+    u64 c_probes, c_keybytes, c_nodes;
+
+    __device__ Tree(const DP &p_, int g_) : p(p_), g(g_) {
+        hdr = p.hdr + (size_t)g * p.node_cap;
+        key = p.key + (size_t)g * p.node_cap * p.KW;
+        size_t eb = (size_t)g * p.edge_cap;
+        eP = p.eP + eb; eQ = p.eQ + eb; eN = p.eN + eb; eChild = p.eChild + eb; eAct = p.eAct + eb;
+        table = p.table + (size_t)g * p.table_cap;
+        wh = p.item_wh + (size_t)g * p.N * 2;
+        n_nodes = p.n_nodes[g];
+        n_edges = p.n_edges[g];
+        c_probes = c_keybytes = c_nodes = 0;
+    }
+    __device__ void store_sizes() {
+        if (lane_id() == 0) { p.n_nodes[g] = n_nodes; p.n_edges[g] = n_edges; }
+    }
+
+    // key of a node -> lane-resident rows + uniform remaining words
+    __device__ void load_key(u32 node, row_t &myrow, u64 &rem0, u64 &rem1) const {
+        const u32 *k = key + (size_t)node * p.KW;
+        myrow = 0;
+        if (lane_id() < p.H) myrow = ((const row_t *)k)[lane_id()];
+        const u32 *rw = k + p.H * p.RW;
+        rem0 = rw[0];
+        if (p.RMW > 1) rem0 |= (u64)rw[1] << 32;
+        rem1 = 0;
+        if (p.RMW > 2) rem1 = rw[2];
+        if (p.RMW > 3) rem1 |= (u64)rw[3] << 32;
+    }
+    __device__ void store_key(u32 node, row_t myrow, u64 rem0, u64 rem1) {
+        u32 *k = key + (size_t)node * p.KW;
+        if (lane_id() < p.H) ((row_t *)k)[lane_id()] = myrow;
+        u32 *rw = k + p.H * p.RW;
+        if (lane_id() < p.RMW) rw[lane_id()] = (u32)((lane_id() < 2 ? rem0 : rem1) >> (32 * (lane_id() & 1)));
+    }
+    __device__ bool key_equals(u32 node, row_t myrow, u64 rem0, u64 rem1) {
+        row_t r2; u64 a0, a1;
+        load_key(node, r2, a0, a1);
+        c_keybytes += (u64)p.KW * 4;
+        return __all((r2 == myrow) && (a0 == rem0) && (a1 == rem1)) != 0;
+    }
+    __device__ u64 hash_state(row_t myrow, u64 rem0, u64 rem1) const {
+        u64 h = lane_id() < p.H ? mix64((u64)myrow + (u64)(lane_id() + 1) * 0x9E3779B97F4A7C15ull) : 0ull;
+        h = wave_xor_u64(h);
+        h ^= mix64(rem0 ^ 0xD1B54A32D192ED03ull) ^ mix64(rem1 + 0x8CB92BA72F3D8DD7ull);
+        return mix64(h);
+    }
+    // s in self.Es ?  -- 64 table slots per probe; returns node id or NONE32 (+ the slot to insert at)
+    __device__ u32 find(row_t myrow, u64 rem0, u64 rem1, u64 h, u32 &insert_slot) {
+        const u32 mask = (u32)p.table_cap - 1u, tag = (u32)(h >> 32);
+        u32 slot = (u32)h & mask;
+        for (int it = 0; it <= p.table_cap / 64; ++it) {
+            u64 e = table[(slot + lane_id()) & mask];
+            c_probes++;
+            u64 empty = __ballot(e == 0ull);
+            u64 hit = __ballot(e != 0ull && (u32)(e >> 32) == tag);
+            int first_empty = empty ? __ffsll((long long)empty) - 1 : 64;
+            u64 cand = hit & (first_empty >= 64 ? ~0ull : ((1ull << first_empty) - 1ull));
+            while (cand) {
+                int l = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                u32 id = (u32)__shfl(e, l) - 1u;
+                if (key_equals(id, myrow, rem0, rem1)) return id;
+            }
+            if (first_empty < 64) { insert_slot = (slot + first_empty) & mask; return NONE32; }
+            slot = (slot + 64) & mask;
+        }
+        if (lane_id() == 0) atomicMax(p.error, ERR_TABLE_FULL);
+        insert_slot = NONE32;
+        return NONE32;
+    }
+    // A state seen for the first time: the Es / Vs part of MCTS.search (MCTS_bpp.py:78-79 getGameEnded ->
+    // has_valid_moves / getRankedReward; :88 getValidMoves).  Allocates the node, stores its key, its legal
+    // moves as an edge run (priors are filled in by the commit kernel after the evaluator ran) or its
+    // terminal value.  Returns the node id or NONE32 on arena overflow.
+    __device__ u32 materialize(row_t myrow, u64 rem0, u64 rem1, u64 h, u32 insert_slot) {
+        if (n_nodes >= (u32)p.node_cap || insert_slot == NONE32) {
+            if (lane_id() == 0) atomicMax(p.error, ERR_NODE_CAP);
+            return NONE32;
+        }
+        const u32 id = n_nodes;
+        store_key(id, myrow, rem0, rem1);
+        ValidSink sink;
+        sink.act = eAct + n_edges; sink.eP = eP + n_edges; sink.eQ = eQ + n_edges; sink.eN = eN + n_edges;
+        sink.eChild = eChild + n_edges; sink.mask = nullptr; sink.cap = p.edge_cap - (int)n_edges;
+        int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
+        if (nv < 0) {
+            if (lane_id() == 0) atomicMax(p.error, ERR_EDGE_CAP);
+            return NONE32;
+        }
+        NodeHdr hd;
+        hd.ns = 0; hd.edge_off = n_edges; hd.n_valid = (u32)nv; hd.term = 0; hd.term_kind = RP_KIND_WEAK; hd.expanded = 0; hd.pad = 0;
+        if (nv == 0) {  // no legal move: game over (BinPackingGame.py:112-114)
+            double r;
+            int e = ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
+            if (e == 2) { e = tie_value<row_t>(myrow, p.H, p.N, rem0, rem1, p.tie_salt); hd.term_kind = RP_KIND_F64; }
+            hd.term = (int8_t)e;
+        }
+        if (lane_id() == 0) {
+            hdr[id] = hd;
+            table[insert_slot] = ((u64)(u32)(h >> 32) << 32) | (u64)(id + 1u);
+        }
+        n_nodes++;
+        n_edges += (u32)nv;
+        c_nodes++;
+        return id;
+    }
+    __device__ u32 find_or_materialize(row_t myrow, u64 rem0, u64 rem1, bool *was_new) {
+        u64 h = hash_state(myrow, rem0, rem1);
+        u32 slot;
+        u32 id = find(myrow, rem0, rem1, h, slot);
+        *was_new = false;
+        if (id == NONE32) { id = materialize(myrow, rem0, rem1, h, slot); *was_new = true; }
+        return id;
+    }
+    // child state of (node, edge): BinPackingGame.getNextState (BinPackingGame.py:58-76)
+    __device__ u32 resolve_child(u32 node, u32 e, bool *was_new) {
+        row_t myrow; u64 rem0, rem1;
+        load_key(node, myrow, rem0, rem1);
+        int a = eAct[e];
+        int i = (int)(((u32)a * p.magicW) >> 20), j = a - i * p.W;
+        myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, wh[2 * i], wh[2 * i + 1]);
+        if (i < 64) rem0 &= ~(1ull << i); else rem1 &= ~(1ull << (i - 64));
+        u32 child = find_or_materialize(myrow, rem0, rem1, was_new);
+        if (lane_id() == 0 && child != NONE32) eChild[e] = child;
+        return child;
+    }
+    // PUCT argmax over the node's edge run (MCTS_bpp.py:106-121), float64, strict '>' in ascending action
+    // order == maximum with the lowest edge index.  Returns the edge index (absolute in the slot arrays).
+    __device__ u32 select_edge(const NodeHdr &hd) const {
+        const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
+        const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
+        double best_u = -INFINITY;
+        u32 best_e = NONE32;
+        for (u32 k = lane_id(); k < hd.n_valid; k += 64) {
+            u32 e = hd.edge_off + k;
+            double cp = p.cpuct * eP[e];
+            u32 nn = eN[e] & NSA_MASK;
+            double u = nn ? eQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
+            if (u > best_u) { best_u = u; best_e = e; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            double ou = __shfl_xor(best_u, o);
+            u32 oe = __shfl_xor(best_e, o);
+            if (ou > best_u || (ou == best_u && oe < best_e)) { best_u = ou; best_e = oe; }
+        }
+        return best_e;
+    }
+    // one lane per path entry (MCTS_bpp.py:130-138)
+    __device__ void backup_entry(u32 node, u32 e, double v, u32 vkind) {
+        u32 nn = eN[e];
+        u32 cnt = nn & NSA_MASK, kind = nn >> 30;
+        double q = eQ[e];
+        q_update(q, kind, cnt, v, vkind);
+        eQ[e] = q;
+        eN[e] = (kind << 30) | (cnt + 1u);
+        hdr[node].ns += 1u;
+    }
+};
+
+__device__ void add_counters(const DP &p, const u64 *c) {
+    if (lane_id() == 0)
+        for (int k = 0; k < CNT_N; ++k)
+            if (c[k]) atomicAdd(p.counters + k, c[k]);
+}
+
+__device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(mix64(seed) ^ episode) ^ move); }
+
+// CoachBPP.executeEpisode's move (CoachBPP.py:86-99) for one slot whose search budget is spent.
+// action < 0: pick by p.move_rule.  Leaves phase RUNNING, EPISODE_DONE or FAILED.
+template <typename row_t>
+__device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, u64 *c) {
+    NodeHdr hd = t.hdr[root];
+    const int lane = lane_id();
+    u32 chosen = NONE32;
+    if (action >= 0) {
+        for (u32 k = lane; k < hd.n_valid + ((64 - hd.n_valid % 64) % 64); k += 64) {
+            bool m = k < hd.n_valid && t.eAct[hd.edge_off + k] == (u16)action;
+            u64 b = __ballot(m);
+            if (b) { chosen = hd.edge_off + (k - lane) + (__ffsll((long long)b) - 1); break; }
+        }
+    } else if (p.move_rule == RP_MOVE_ARGMAX_FIRST) {
+        u32 best_n = 0, best_e = NONE32;
+        for (u32 k = lane; k < hd.n_valid; k += 64) {
+            u32 n = t.eN[hd.edge_off + k] & NSA_MASK;
+            if (n > best_n) { best_n = n; best_e = hd.edge_off + k; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            u32 on = __shfl_xor(best_n, o), oe = __shfl_xor(best_e, o);
+            if (on > best_n || (on == best_n && oe < best_e)) { best_n = on; best_e = oe; }
+        }
+        chosen = best_n ? best_e : NONE32;
+    } else {  // RP_MOVE_SAMPLE: a ~ counts, inverse CDF over the edge run in action order
+        u64 total = 0;
+        for (u32 k = lane; k < hd.n_valid; k += 64) total += t.eN[hd.edge_off + k] & NSA_MASK;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+        if (total) {
+            u64 x = sample_u64(p.seed, p.episode[g], (u64)p.moves[g]);
+            u64 r = __umul64hi(x, total), acc = 0;
+            for (u32 kb = 0; kb < hd.n_valid && chosen == NONE32; kb += 64) {
+                u32 k = kb + lane;
+                u64 n = k < hd.n_valid ? (u64)(t.eN[hd.edge_off + k] & NSA_MASK) : 0ull;
+                u64 pre = n;  // inclusive prefix sum over the 64 lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    u64 up = __shfl_up(pre, o);
+                    if (lane >= o) pre += up;
+                }
+                u64 b = __ballot(acc + pre > r);
+                if (b) chosen = hd.edge_off + kb + (__ffsll((long long)b) - 1);
+                acc += __shfl(pre, 63);
+            }
+        }
+    }
+    if (chosen == NONE32) {
+        if (lane == 0) { atomicMax(p.error, ERR_BAD_ACTION); p.phase[g] = RP_PHASE_FAILED; }
+        return;
+    }
+    u32 child = t.eChild[chosen];
+    if (child == NONE32) {
+        bool was_new;
+        child = t.resolve_child(root, chosen, &was_new);
+        wave_sync();
+        if (child == NONE32) { if (lane == 0) p.phase[g] = RP_PHASE_FAILED; return; }
+    }
+    if (p.max_examples > 0) {  // trainExamples.append([state, pi, None]) (CoachBPP.py:80)
+        unsigned long long idx = 0;
+        if (lane == 0) idx = atomicAdd(p.ex_count, 1ull);
+        idx = __shfl(idx, 0);
+        int mv = p.moves[g];
+        if ((long long)idx < p.max_examples && mv < p.N) {
+            const u32 *k = t.key + (size_t)root * p.KW;
+            u32 *ek = p.ex_key + (size_t)idx * p.KW;
+            for (int q = lane; q < p.KW; q += 64) ek[q] = k[q];
+            u8 *ew = p.ex_wh + (size_t)idx * p.N * 2;
+            for (int q = lane; q < 2 * p.N; q += 64) ew[q] = t.wh[q];
+            u32 *ec = p.ex_counts + (size_t)idx * p.A;
+            for (int a = lane; a < p.A; a += 64) ec[a] = 0u;
+            wave_sync();
+            for (u32 q = lane; q < hd.n_valid; q += 64) ec[t.eAct[hd.edge_off + q]] = t.eN[hd.edge_off + q] & NSA_MASK;
+            if (lane == 0) { p.ex_value[idx] = 0; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
+        } else if (lane == 0) {
+            atomicMax(p.error, ERR_EXAMPLES_CAP);
+        }
+    }
+    root = child;
+    c[CNT_MOVES]++;
+    NodeHdr ch = t.hdr[child];
+    int moves = p.moves[g] + 1;
+    if (lane == 0) { p.root[g] = root; p.moves[g] = moves; p.sims_done[g] = 0; }
+    if (ch.term != 0) {  // getGameEnded(next_state) != 0 (CoachBPP.py:91-99)
+        row_t myrow; u64 rem0, rem1;
+        t.load_key(child, myrow, rem0, rem1);
+        double r;
+        ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
+        c[CNT_EPISODES]++;
+        if (p.max_examples > 0)  // return [(x[0], x[1], r) for x in trainExamples] (CoachBPP.py:99)
+            for (int q = lane; q < moves && q < p.N; q += 64) {
+                u32 idx = p.slot_ex[(size_t)g * p.N + q];
+                if ((long long)idx < p.max_examples) p.ex_value[idx] = ch.term;
+            }
+        if (lane == 0) {
+            p.last_outcome[g] = ch.term;
+            p.last_score[g] = r;
+            p.phase[g] = RP_PHASE_EPISODE_DONE;
+            int idx = atomicAdd(p.fin_count, 1);
+            if (idx < p.fin_cap) {
+                p.fin_episode[idx] = p.episode[g]; p.fin_outcome[idx] = ch.term; p.fin_score[idx] = r; p.fin_moves[idx] = moves;
+            } else {
+                atomicMax(p.error, ERR_FINISHED_CAP);
+            }
+        }
+    } else if (lane == 0) {
+        p.last_outcome[g] = 0;
+        p.last_score[g] = 0.0;
+        p.phase[g] = RP_PHASE_RUNNING;
+    }
+}
+
+// A slot whose episode ended takes the next instance of the pool (CoachBPP.py:123-134: the next self-play
+// episode, a new MCTS with an empty tree).  Leaves the slot RUNNING at the new root, or IDLE when the pool is used up.
+template <typename row_t>
+__device__ void restart_slot(const DP &p, Tree<row_t> &t, int g, u32 &root, u64 *c) {
+    const int lane = lane_id();
+    unsigned long long idx = 0;
+    if (lane == 0) idx = atomicAdd(p.next_instance, 1ull);
+    idx = __shfl(idx, 0);
+    if ((long long)idx >= p.n_instances) {
+        if (lane == 0) p.phase[g] = RP_PHASE_IDLE;
+        return;
+    }
+    u8 *wh = p.item_wh + (size_t)g * p.N * 2;
+    const u8 *src = p.pool_wh + (size_t)idx * p.N * 2;
+    for (int q = lane; q < 2 * p.N; q += 64) wh[q] = src[q];
+    for (int s = lane; s < p.table_cap; s += 64) t.table[s] = 0ull;
+    if (lane == 0) {
+        p.total_area[g] = p.pool_area[idx]; p.max_h[g] = p.pool_max_h[idx];
+        p.episode[g] = p.first_id + idx; p.moves[g] = 0; p.sims_done[g] = 0;
+        p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;
+        p.last_outcome[g] = 0; p.last_score[g] = 0.0;
+    }
+    t.n_nodes = 0; t.n_edges = 0;
+    wave_sync();
+    bool was_new;
+    row_t myrow = 0;
+    u64 rem0 = full_mask(p.N > 64 ? 64 : p.N), rem1 = p.N > 64 ? full_mask(p.N - 64) : 0ull;
+    root = t.find_or_materialize(myrow, rem0, rem1, &was_new);
+    wave_sync();
+    if (lane == 0) { p.root[g] = root; p.phase[g] = root == NONE32 ? RP_PHASE_FAILED : RP_PHASE_RUNNING; }
+    (void)c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// MCTS.search (MCTS_bpp.py:56-139) for all slots: each wave runs simulations of its game until one
+// needs the evaluator or the move's budget is spent.
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    if (g >= p.G) return;
+    int phase = p.phase[g];
+    if (phase != RP_PHASE_RUNNING && !(phase == RP_PHASE_MOVE_READY && p.move_rule != RP_MOVE_EXTERNAL)) return;
+    Tree<row_t> t(p, g);
+    u64 c[CNT_N];
+    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
+    u32 root = p.root[g];
+    int sims_done = p.sims_done[g];
+    for (;;) {
+        if (phase == RP_PHASE_MOVE_READY) {
+            if (p.move_rule == RP_MOVE_EXTERNAL) break;
+            play_move<row_t>(p, t, g, root, -1, c);
+            wave_sync();
+            phase = p.phase[g];
+            if (phase == RP_PHASE_EPISODE_DONE && p.auto_restart) {
+                restart_slot<row_t>(p, t, g, root, c);
+                wave_sync();
+                phase = p.phase[g];
+            }
+            sims_done = 0;
+            if (phase != RP_PHASE_RUNNING) break;
+        }
+        if (sims_done >= p.sims) {  // for i in range(numMCTSSims) done (MCTS_bpp.py:37-38)
+            phase = RP_PHASE_MOVE_READY;
+            if (lane == 0) { p.phase[g] = phase; p.sims_done[g] = sims_done; }
+            wave_sync();
+            continue;
+        }
+        // ---- one simulation ----
+        u32 node = root, pe0 = NONE32, pn0 = NONE32, pe1 = NONE32, pn1 = NONE32;
+        int depth = 0;
+        double v = 0.0;
+        u32 vkind = RP_KIND_WEAK;
+        bool need_eval = false, failed = false;
+        for (;;) {
+            NodeHdr hd = t.hdr[node];
+            if (hd.term != 0) {  // :81-83
+                v = (double)hd.term; vkind = hd.term_kind; c[CNT_TERMINAL]++;
+                break;
+            }
+            if (!hd.expanded) { need_eval = true; break; }  // :85 leaf
+            u32 e = t.select_edge(hd);
+            if (e == NONE32 || depth >= p.N) { failed = true; break; }
+            if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
+            else if (lane == depth - 64) { pe1 = e; pn1 = node; }
+            depth++;
+            c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid;
+            u32 child = t.eChild[e];
+            if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
+                bool was_new;
+                child = t.resolve_child(node, e, &was_new);
+                if (child == NONE32) { failed = true; break; }
+                if (!was_new) c[CNT_TRANSPOSE]++;
+                wave_sync();
+            }
+            node = child;
+        }
+        if (failed) {
+            if (lane == 0) { atomicMax(p.error, ERR_PATH); }
+            phase = RP_PHASE_FAILED;
+            break;
+        }
+        if (need_eval) {  // hand the leaf to the evaluator (nnet.predict, :87); commit kernel finishes the simulation
+            u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
+            if (lane < depth) { pe[lane] = pe0; pn[lane] = pn0; }
+            if (lane + 64 < depth) { pe[lane + 64] = pe1; pn[lane + 64] = pn1; }
+            if (lane == 0) {
+                p.leaf_node[g] = node;
+                p.path_len[g] = depth;
+                int b = atomicAdd(p.eval_count, 1);
+                p.eval_slot[b] = g;
+                p.game_row[g] = b;
+            }
+            phase = RP_PHASE_WAIT_EVAL;
+            break;
+        }
+        if (lane < depth) t.backup_entry(pn0, pe0, v, vkind);
+        if (lane + 64 < depth) t.backup_entry(pn1, pe1, v, vkind);
+        sims_done++;
+        c[CNT_SIMS]++;
+        wave_sync();
+    }
+    t.store_sizes();
+    c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
+    if (lane == 0) {
+        if (phase != RP_PHASE_EPISODE_DONE && phase != RP_PHASE_IDLE) p.phase[g] = phase;
+        if (phase == RP_PHASE_WAIT_EVAL || phase == RP_PHASE_FAILED) p.sims_done[g] = sims_done;
+    }
+    add_counters(p, c);
+}
+
+// np.sum(Ps[s]) over the dense A-vector in NumPy's pairwise order (MCTS_bpp.py:90,100).  mode 0:
+// x[a] = float64(pi[a]) * valid[a]; mode 1 (fallback): x[a] = float64(pi[a]) * valid[a] + valid[a].
+__device__ __forceinline__ double prior_term(const float *pi, const u32 *vmask, int a, int mode) {
+    double valid = (double)((vmask[a >> 5] >> (a & 31)) & 1u);
+    double x = (double)pi[a] * valid;
+    return mode ? x + valid : x;
+}
+__device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmask, double *sleaf, int mode) {
+    const int lane = lane_id(), j = lane & 7;
+    for (int lb = 0; lb < p.n_leaves; lb += 8) {
+        int l = lb + (lane >> 3);
+        bool act = l < p.n_leaves;
+        int lo = act ? p.leaf_lo[l] : 0, n = act ? p.leaf_n[l] : 0;
+        double res = 0.0;
+        if (n >= 8) {
+            int n8 = n - (n & 7);
+            double r = prior_term(pi, vmask, lo + j, mode);
+            for (int i = 8 + j; i < n8; i += 8) r = r + prior_term(pi, vmask, lo + i, mode);
+            double s1 = r + __shfl_down(r, 1);     // r0+r1, r2+r3, ...
+            double s2 = s1 + __shfl_down(s1, 2);   // (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+            double s3 = s2 + __shfl_down(s2, 4);
+            res = s3;
+            if (j == 0)
+                for (int i = n8; i < n; ++i) res = res + prior_term(pi, vmask, lo + i, mode);
+        } else {
+            if (act && j == 0) {
+                res = -0.0;
+                for (int i = 0; i < n; ++i) res = res + prior_term(pi, vmask, lo + i, mode);
+            }
+        }
+        if (act && j == 0) sleaf[l] = res;
+    }
+    wave_sync();
+    if (lane == 0)
+        for (int k = 0; k < p.n_leaves - 1; ++k) sleaf[p.sched_dst[k]] = sleaf[p.sched_dst[k]] + sleaf[p.sched_src[k]];
+    wave_sync();
+    double total = sleaf[0];
+    wave_sync();
+    return total;
+}
+
+// fills P for one node from the evaluator's pi (MCTS_bpp.py:87-100)
+__device__ void masked_prior(const DP &p, const float *pi, const u16 *act, double *P, u32 n_valid, u32 *vmask, double *sleaf) {
+    const int lane = lane_id();
+    const int words = (p.A + 31) >> 5;
+    for (int w = lane; w < words; w += 64) vmask[w] = 0u;
+    wave_sync();
+    for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); }
+    wave_sync();
+    double s = numpy_masked_sum(p, pi, vmask, sleaf, 0);
+    if (s > 0) {  // :91-92
+        for (u32 k = lane; k < n_valid; k += 64) P[k] = ((double)pi[act[k]] * 1.0) / s;
+    } else {  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
+        double s2 = numpy_masked_sum(p, pi, vmask, sleaf, 1);
+        for (u32 k = lane; k < n_valid; k += 64) P[k] = ((double)pi[act[k]] * 1.0 + 1.0) / s2;
+    }
+}
+
+// Expansion + backup for the waiting leaves (MCTS_bpp.py:87-104 then :130-139 up the path).
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const float *pi, const float *vv) {
+    __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
+    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id(), wv = threadIdx.x >> 6;
+    if (b >= *p.eval_count) return;
+    const int g = p.eval_slot[b];
+    Tree<row_t> t(p, g);
+    const u32 node = p.leaf_node[g];
+    NodeHdr hd = t.hdr[node];
+    masked_prior(p, pi + (size_t)b * p.A, t.eAct + hd.edge_off, t.eP + hd.edge_off, hd.n_valid, s_mask[wv], s_leaf[wv]);
+    if (lane == 0) { hd.expanded = 1; hd.ns = 0; t.hdr[node] = hd; }  // Vs[s] = valids; Ns[s] = 0 (:102-103)
+    const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
+    const int depth = p.path_len[g];
+    const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
+    for (int d = lane; d < depth; d += 64) t.backup_entry(pn[d], pe[d], v, RP_KIND_F32);
+    u64 c[CNT_N];
+    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
+    c[CNT_SIMS] = 1; c[CNT_EXPAND] = 1; c[CNT_NVALID_LEAF] = hd.n_valid;
+    if (lane == 0) { p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; }
+    add_counters(p, c);
+}
+
+// Evaluator input of the waiting leaves: getBinItem's (N+1, H, W) planes as float32 (BinPackingGame.py:118-120,
+// NNet.py:77-79): plane 0 = grid, plane i+1 = item i as ones in [0:h, 0:w] while unplaced (BinPackingGame.py:45,55).
+template <typename row_t>
+__device__ void write_planes(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u64 rem1, float *out) {
+    const int HW = p.H * p.W, lane = lane_id();
+    for (int base = 0; base < HW; base += 64) {  // plane 0
+        int idx = base + lane;
+        int r = (int)(((u32)idx * p.magicW) >> 20), x = idx - r * p.W;
+        row_t rr = __shfl(myrow, r & 63);
+        if (idx < HW) out[idx] = (float)((rr >> x) & 1);
+    }
+    for (int i = 0; i < p.N; ++i) {
+        float *pl = out + (size_t)(i + 1) * HW;
+        bool unplaced = ((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull) != 0;
+        int w = unplaced ? wh[2 * i] : 0, h = unplaced ? wh[2 * i + 1] : 0;
+        for (int idx = lane; idx < HW; idx += 64) {
+            int r = (int)(((u32)idx * p.magicW) >> 20), x = idx - r * p.W;
+            pl[idx] = (r < h && x < w) ? 1.0f : 0.0f;
+        }
+    }
+}
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_planes(DP p, float *planes, long long capacity_rows) {
+    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= *p.eval_count || b >= capacity_rows) return;
+    const int g = p.eval_slot[b];
+    Tree<row_t> t(p, g);
+    row_t myrow; u64 rem0, rem1;
+    t.load_key(p.leaf_node[g], myrow, rem0, rem1);
+    write_planes<row_t>(p, t.wh, myrow, rem0, rem1, planes + (size_t)b * (p.N + 1) * p.H * p.W);
+}
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_states(DP p, u64 *rows_out, u8 *rem_out, int *slot_out, int max_rows) {
+    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    if (b >= *p.eval_count || b >= max_rows) return;
+    const int g = p.eval_slot[b];
+    Tree<row_t> t(p, g);
+    row_t myrow; u64 rem0, rem1;
+    t.load_key(p.leaf_node[g], myrow, rem0, rem1);
+    if (lane < p.H) rows_out[(size_t)b * p.H + lane] = (u64)myrow;
+    for (int i = lane; i < p.N; i += 64) rem_out[(size_t)b * p.N + i] = (u8)((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull);
+    if (lane == 0) slot_out[b] = g;
+}
+
+// host-provided state -> lane-resident form
+template <typename row_t>
+__device__ void load_host_state(const DP &p, const u64 *rows, const u8 *rem, row_t &myrow, u64 &rem0, u64 &rem1) {
+    const int lane = lane_id();
+    myrow = lane < p.H ? (row_t)rows[lane] : (row_t)0;
+    rem0 = __ballot(lane < p.N && rem[lane] != 0);
+    rem1 = __ballot(lane + 64 < p.N && rem[lane + 64 < p.N ? lane + 64 : 0] != 0);
+}
+
+// New episodes: empty tree, empty board, all items unplaced (CoachBPP.py:67-68,124); or re-rooting at a
+// given state while keeping the tree (rows != nullptr).
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int first, int count, const u64 *rows, const u8 *rem, int clear_tree) {
+    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    if (k >= count) return;
+    const int g = first + k;
+    if (clear_tree) {
+        u64 *tab = p.table + (size_t)g * p.table_cap;
+        for (int s = lane; s < p.table_cap; s += 64) tab[s] = 0ull;
+        if (lane == 0) {
+            p.n_nodes[g] = 0; p.n_edges[g] = 0; p.moves[g] = 0;
+            p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;  // rewards_list snapshot for this episode
+            p.last_outcome[g] = 0; p.last_score[g] = 0.0;
+        }
+        wave_sync();
+    }
+    Tree<row_t> t(p, g);
+    row_t myrow; u64 rem0, rem1;
+    if (rows) {
+        load_host_state<row_t>(p, rows + (size_t)k * p.H, rem + (size_t)k * p.N, myrow, rem0, rem1);
+    } else {
+        myrow = 0; rem0 = full_mask(p.N > 64 ? 64 : p.N); rem1 = p.N > 64 ? full_mask(p.N - 64) : 0ull;
+    }
+    bool was_new;
+    u32 id = t.find_or_materialize(myrow, rem0, rem1, &was_new);
+    t.store_sizes();
+    u64 c[CNT_N];
+    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
+    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
+    add_counters(p, c);
+    if (lane == 0) {
+        p.root[g] = id;
+        p.sims_done[g] = 0;
+        p.phase[g] = id == NONE32 ? RP_PHASE_FAILED : RP_PHASE_RUNNING;
+    }
+}
+
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int first, int count, const int *action) {
+    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= count) return;
+    const int g = first + k;
+    int phase = p.phase[g];
+    if (phase != RP_PHASE_MOVE_READY && phase != RP_PHASE_RUNNING) return;
+    Tree<row_t> t(p, g);
+    u64 c[CNT_N];
+    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
+    u32 root = p.root[g];
+    play_move<row_t>(p, t, g, root, action[k], c);
+    t.store_sizes();
+    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
+    add_counters(p, c);
+}
+
+// counts[a] = Nsa[(root, a)] (MCTS_bpp.py:40-41)
+__global__ void k_root_counts(DP p, int first, int count, u32 *out) {
+    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    if (k >= count) return;
+    const int g = first + k;
+    u32 *o = out + (size_t)k * p.A;
+    for (int a = lane; a < p.A; a += 64) o[a] = 0u;
+    wave_sync();
+    u32 root = p.root[g];
+    if (root == NONE32) return;
+    NodeHdr hd = p.hdr[(size_t)g * p.node_cap + root];
+    size_t eb = (size_t)g * p.edge_cap + hd.edge_off;
+    for (u32 e = lane; e < hd.n_valid; e += 64) o[p.eAct[eb + e]] = p.eN[eb + e] & NSA_MASK;
+}
+
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    Tree<row_t> t(p, g);
+    u64 c[CNT_N];
+    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
+    u32 root = NONE32;
+    restart_slot<row_t>(p, t, g, root, c);
+    t.store_sizes();
+    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
+    add_counters(p, c);
+}
+
+// Training tensors of recorded examples: planes as getBinItem (BinPackingGame.py:118-120), pi = counts / sum in
+// float64 rounded to float32 (MCTS_bpp.py:51-54 then torch.FloatTensor, NNet.py:46), value = ranked outcome.
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, long long first, long long count, float *planes, float *pi, float *value) {
+    const long long k = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= count) return;
+    const long long idx = first + k;
+    const int lane = lane_id();
+    const u32 *key = p.ex_key + (size_t)idx * p.KW;
+    row_t myrow = lane < p.H ? ((const row_t *)key)[lane] : (row_t)0;
+    const u32 *rw = key + p.H * p.RW;
+    u64 rem0 = rw[0], rem1 = 0;
+    if (p.RMW > 1) rem0 |= (u64)rw[1] << 32;
+    if (p.RMW > 2) rem1 = rw[2];
+    if (p.RMW > 3) rem1 |= (u64)rw[3] << 32;
+    write_planes<row_t>(p, p.ex_wh + (size_t)idx * p.N * 2, myrow, rem0, rem1, planes + (size_t)k * (p.N + 1) * p.H * p.W);
+    const u32 *cn = p.ex_counts + (size_t)idx * p.A;
+    u64 total = 0;
+    for (int a = lane; a < p.A; a += 64) total += cn[a];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
+    const double ds = (double)total;  // counts_sum = float(sum(counts))
+    for (int a = lane; a < p.A; a += 64) pi[(size_t)k * p.A + a] = (float)((double)cn[a] / ds);
+    if (lane == 0) value[k] = (float)p.ex_value[idx];
+}
+
+// ---- stateless rule kernels (one wave per state) ----
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, u8 *mask, int *nvalid) {
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    row_t myrow; u64 rem0, rem1;
+    load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
+    ValidSink sink;
+    sink.act = nullptr; sink.eP = sink.eQ = nullptr; sink.eN = sink.eChild = nullptr; sink.mask = mask + b * p.A; sink.cap = 0;
+    int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
+    if (nvalid && lane_id() == 0) nvalid[b] = nv;
+}
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_apply_move(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, const int *action,
+                                                                      u64 *rows_out, u8 *rem_out, int *status) {
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id();
+    row_t myrow; u64 rem0, rem1;
+    load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
+    int a = action[b];
+    int st = 0;
+    if (a < 0 || a >= p.A) {
+        st = RP_ERR_ARG;
+    } else {
+        int i = a / p.W, j = a % p.W;  // int(action / W), int(action % W) (BinPackingGame.py:67)
+        bool unplaced = ((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull) != 0;
+        if (!unplaced) {
+            st = RP_ERR_ASSERT;  // BinPackingGame.py:69
+        } else {
+            const u8 *w2 = wh + b * p.N * 2;
+            myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, w2[2 * i], w2[2 * i + 1]);
+            if (i < 64) rem0 &= ~(1ull << i); else rem1 &= ~(1ull << (i - 64));
+        }
+    }
+    if (lane < p.H) rows_out[b * p.H + lane] = (u64)myrow;
+    for (int i = lane; i < p.N; i += 64) rem_out[b * p.N + i] = (u8)((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull);
+    if (lane == 0) status[b] = st;
+}
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, const int *area,
+                                                                      const int *max_h, int has_buf, double bl, int *ended, double *reward) {
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    row_t myrow; u64 rem0, rem1;
+    load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
+    ValidSink sink;
+    sink.act = nullptr; sink.eP = sink.eQ = nullptr; sink.eN = sink.eChild = nullptr; sink.mask = nullptr; sink.cap = 0;
+    int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
+    double r = 0.0;
+    int e = 0;
+    if (nv == 0) e = ranked_reward<row_t>(myrow, p.H, p.W, area[b], max_h[b], has_buf != 0, bl, &r);
+    if (lane_id() == 0) { ended[b] = e; reward[b] = r; }
+}
+
+// ---- device self-tests ----
+__global__ void k_selftest_sqrt(long long n, double *a, double *b) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = sqrt((double)(u32)i); b[i] = sqrt((double)(u32)i + 1e-8); }
+}
+__global__ void k_selftest_q(long long n, const double *q, const u8 *qk, const u32 *nsa, const double *v, const u8 *vk, double *qo, u8 *qko) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double x = q[i]; u32 k = qk[i];
+        q_update(x, k, nsa[i], v[i], vk[i]);
+        qo[i] = x; qko[i] = (u8)k;
+    }
+}
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, long long B, const float *pi, const u8 *valid, double *out, u16 *act_scratch) {
+    __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    u16 *act = act_scratch + b * p.A;
+    double *o = out + b * p.A;
+    int nv = 0;
+    for (int base = 0; base < p.A; base += 64) {  // compact the valid actions in order
+        int a = base + lane;
+        bool ok = a < p.A && valid[b * p.A + a] != 0;
+        u64 m = __ballot(ok);
+        if (ok) act[nv + __popcll(m & lanes_below())] = (u16)a;
+        if (a < p.A) o[a] = 0.0;
+        nv += __popcll(m);
+    }
+    wave_sync();
+    // masked_prior writes compact priors P[k], k < nv, into the front of the (zeroed) dense row ...
+    masked_prior(p, pi + b * p.A, act, o, (u32)nv, s_mask[wv], s_leaf[wv]);
+    wave_sync();
+    // ... which are then expanded in place from the back (act[k] >= k always)
+    for (int k = nv - 1; k >= 0; --k) {
+        if (lane == 0) { double x = o[k]; o[k] = 0.0; o[act[k]] = x; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct rp_ctx {
+    rp_config cfg;
+    DP d;
+    hipStream_t stream;
+    bool row64;
+    std::string err;
+    std::vector<void *> allocs;
+    int64_t bytes;
+    int64_t fin_popped;
+    u8 *pool_wh;
+    int *pool_area, *pool_max_h;
+    int64_t pool_cap;
+};
+
+static std::string g_create_error;
+
+static int fail(rp_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T> static int dev_alloc(rp_ctx *ctx, T **out, size_t n, bool zero = true) {
+    void *ptr = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(ctx, hipMalloc(&ptr, bytes));
+    ctx->allocs.push_back(ptr);
+    ctx->bytes += (int64_t)bytes;
+    if (zero) HIPCHK(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
+    *out = (T *)ptr;
+    return RP_OK;
+}
+#define ALLOC(ctx, ptr, n)                       \
+    do {                                         \
+        int rc_ = dev_alloc(ctx, &(ptr), (n));   \
+        if (rc_ != RP_OK) return rc_;            \
+    } while (0)
+
+static int grid_for(long long waves) { return (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+
+static int check_device_error(rp_ctx *ctx) {
+    int e = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&e, ctx->d.error, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (e == 0) return RP_OK;
+    static const char *names[] = {"", "node arena overflow (raise node_cap)", "edge arena overflow (raise edge_cap)",
+                                  "transposition table full", "action is not a legal move of the root", "search path broken",
+                                  "finished-episode ring overflow", "replay buffer full (raise max_examples)"};
+    int code = (e == ERR_BAD_ACTION) ? RP_ERR_ASSERT : (e == ERR_PATH ? RP_ERR_STATE : RP_ERR_CAPACITY);
+    return fail(ctx, code, "device error %d: %s", e, e < 8 ? names[e] : "?");
+}
+
+// leaves and combine schedule of NumPy's pairwise sum over n elements (oracle: pairwise_sum)
+static int build_plan(int lo, int n, std::vector<int> &llo, std::vector<int> &ln, std::vector<int> &sd, std::vector<int> &ss) {
+    if (n <= 128) {
+        llo.push_back(lo); ln.push_back(n);
+        return (int)llo.size() - 1;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    int a = build_plan(lo, n2, llo, ln, sd, ss);
+    int b = build_plan(lo + n2, n - n2, llo, ln, sd, ss);
+    sd.push_back(a); ss.push_back(b);
+    return a;
+}
+
+extern "C" int rp_version(void) { return RP_ABI_VERSION; }
+
+extern "C" const char *rp_last_error(const rp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int64_t rp_device_bytes(const rp_ctx *ctx) { return ctx ? ctx->bytes : 0; }
+
+extern "C" void rp_destroy(rp_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->cfg.device);
+    hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs) hipFree(p);
+    delete ctx;
+}
+
+extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, RP_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != RP_ABI_VERSION) return fail(nullptr, RP_ERR_ARG, "abi_version %d != %d", cfg->abi_version, RP_ABI_VERSION);
+    if (cfg->W < 1 || cfg->W > 64 || cfg->H < 1 || cfg->H > 64 || cfg->N < 1 || cfg->N > 128)
+        return fail(nullptr, RP_ERR_ARG, "limits: 1<=W<=64, 1<=H<=64, 1<=N<=128 (got %d %d %d)", cfg->W, cfg->H, cfg->N);
+    if (cfg->games < 1 || cfg->sims < 0) return fail(nullptr, RP_ERR_ARG, "games >= 1 and sims >= 0 required");
+    if ((int64_t)cfg->sims * (cfg->N + 1) >= (int64_t)NSA_MASK) return fail(nullptr, RP_ERR_ARG, "sims too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device)
+        return fail(nullptr, RP_ERR_DEVICE, "no HIP device %d (found %d): the engine has no CPU fallback", cfg->device, ndev);
+    rp_ctx *ctx = new rp_ctx();
+    ctx->cfg = *cfg;
+    ctx->bytes = 0;
+    ctx->fin_popped = 0;
+    ctx->pool_wh = nullptr; ctx->pool_area = nullptr; ctx->pool_max_h = nullptr; ctx->pool_cap = 0;
+    ctx->stream = (hipStream_t)cfg->stream;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, RP_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e)); }
+    DP &d = ctx->d;
+    memset(&d, 0, sizeof d);
+    d.W = cfg->W; d.H = cfg->H; d.N = cfg->N; d.A = cfg->W * cfg->N; d.G = cfg->games; d.sims = cfg->sims;
+    d.cpuct = cfg->cpuct; d.seed = cfg->seed; d.tie_salt = cfg->tie_salt; d.move_rule = cfg->move_rule;
+    d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (cfg->N + 1) + 2;
+    d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 64) + d.A;
+    int tc = 64;
+    while (tc < 2 * d.node_cap) tc *= 2;
+    d.table_cap = tc;
+    ctx->row64 = cfg->W > 32;
+    d.RW = ctx->row64 ? 2 : 1;
+    d.RMW = (cfg->N + 31) / 32;
+    d.KW = cfg->H * d.RW + d.RMW;
+    if (ctx->row64 && (d.KW & 1)) d.KW++;  // keep 64-bit rows 8-byte aligned
+    d.magicW = (u32)(((1u << 20) + cfg->W - 1) / cfg->W);
+    for (u32 a = 0; a < 8192u; ++a)
+        if (((a * d.magicW) >> 20) != a / (u32)cfg->W) { delete ctx; return fail(nullptr, RP_ERR_ARG, "internal: division magic"); }
+    const size_t G = (size_t)d.G, N = (size_t)d.N;
+    int rc = RP_OK;
+    auto A_ = [&](auto &ptr, size_t n) { if (rc == RP_OK) rc = dev_alloc(ctx, &ptr, n); };
+    A_(d.item_wh, G * N * 2); A_(d.total_area, G); A_(d.max_h, G); A_(d.bl, G); A_(d.has_buf, G);
+    A_(d.root, G); A_(d.n_nodes, G); A_(d.n_edges, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
+    A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
+    A_(d.last_outcome, G); A_(d.last_score, G);
+    A_(d.eval_count, 1); A_(d.eval_slot, G);
+    A_(d.hdr, G * d.node_cap); A_(d.key, G * d.node_cap * d.KW);
+    A_(d.eP, G * d.edge_cap); A_(d.eQ, G * d.edge_cap); A_(d.eN, G * d.edge_cap); A_(d.eChild, G * d.edge_cap); A_(d.eAct, G * d.edge_cap);
+    A_(d.table, G * d.table_cap);
+    A_(d.g_bl, 1); A_(d.g_has_buf, 1); A_(d.counters, CNT_N); A_(d.error, 1);
+    d.fin_cap = (int)std::max<size_t>(4 * G, 1024);
+    A_(d.fin_count, 1); A_(d.fin_episode, d.fin_cap); A_(d.fin_outcome, d.fin_cap); A_(d.fin_moves, d.fin_cap); A_(d.fin_score, d.fin_cap);
+    d.auto_restart = cfg->auto_restart; d.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
+    A_(d.next_instance, 1); A_(d.ex_count, 1); A_(d.slot_ex, G * N);
+    if (d.max_examples > 0) {
+        A_(d.ex_key, (size_t)d.max_examples * d.KW); A_(d.ex_wh, (size_t)d.max_examples * N * 2);
+        A_(d.ex_counts, (size_t)d.max_examples * d.A); A_(d.ex_value, (size_t)d.max_examples);
+    }
+    std::vector<int> llo, ln, sd, ss;
+    build_plan(0, d.A, llo, ln, sd, ss);
+    if ((int)llo.size() > MAX_LEAVES) rc = fail(nullptr, RP_ERR_ARG, "action space too large");
+    int *plan = nullptr;
+    size_t L = llo.size(), S = sd.size();
+    A_(plan, 2 * L + 2 * S + 4);
+    if (rc != RP_OK) {
+        std::string msg = ctx->err.empty() ? g_create_error : ctx->err;
+        for (void *p : ctx->allocs) hipFree(p);
+        delete ctx;
+        return fail(nullptr, rc, "rp_create: %s (needs about %.1f GiB of HBM)", msg.c_str(),
+                    (double)(G * ((size_t)d.node_cap * (16 + 4 * d.KW) + (size_t)d.edge_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
+    }
+    d.n_leaves = (int)L;
+    d.leaf_lo = plan; d.leaf_n = plan + L; d.sched_dst = plan + 2 * L; d.sched_src = plan + 2 * L + S;
+    std::vector<int> hp;
+    hp.insert(hp.end(), llo.begin(), llo.end()); hp.insert(hp.end(), ln.begin(), ln.end());
+    hp.insert(hp.end(), sd.begin(), sd.end()); hp.insert(hp.end(), ss.begin(), ss.end());
+    if (hipMemcpyAsync(plan, hp.data(), hp.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        for (void *p : ctx->allocs) hipFree(p);
+        delete ctx;
+        return fail(nullptr, RP_ERR_DEVICE, "rp_create: plan upload failed");
+    }
+    *out = ctx;
+    return RP_OK;
+}
+
+#define DISPATCH(ctx, kernel, grid, ...)                                                                   \
+    do {                                                                                                   \
+        if ((ctx)->row64) hipLaunchKernelGGL(kernel<u64>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel<u32>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, (ctx)->stream, __VA_ARGS__);              \
+        hipError_t le_ = hipGetLastError();                                                                \
+        if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of %s failed: %s", #kernel, hipGetErrorString(le_)); \
+    } while (0)
+
+// scratch device copies of host inputs for the stateless calls
+struct Scratch {
+    rp_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit Scratch(rp_ctx *c) : ctx(c) {}
+    ~Scratch() { for (void *p : ptrs) hipFree(p); }
+    template <typename T> T *up(const T *host, size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (host && hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+        return (T *)p;
+    }
+};
+#define NEED(ptr) do { if (!(ptr)) return fail(ctx, RP_ERR_DEVICE, "scratch allocation / upload failed"); } while (0)
+
+extern "C" int rp_valid_moves(rp_ctx *ctx, int64_t B, const uint64_t *rows, const uint8_t *remaining, const uint8_t *item_wh,
+                              uint8_t *mask_out, int32_t *n_valid_out) {
+    if (!ctx || B < 0 || !rows || !remaining || !item_wh || !mask_out) return fail(ctx, RP_ERR_ARG, "rp_valid_moves: bad argument");
+    if (B == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    u64 *drows = s.up((const u64 *)rows, (size_t)B * d.H); NEED(drows);
+    u8 *drem = s.up(remaining, (size_t)B * d.N); NEED(drem);
+    u8 *dwh = s.up(item_wh, (size_t)B * d.N * 2); NEED(dwh);
+    u8 *dmask = s.up((const u8 *)nullptr, (size_t)B * d.A); NEED(dmask);
+    int *dnv = s.up((const int *)nullptr, (size_t)B); NEED(dnv);
+    DISPATCH(ctx, k_valid_moves, grid_for(B), d, (long long)B, drows, drem, dwh, dmask, dnv);
+    HIPCHK(ctx, hipMemcpyAsync(mask_out, dmask, (size_t)B * d.A, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_valid_out) HIPCHK(ctx, hipMemcpyAsync(n_valid_out, dnv, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_apply_move(rp_ctx *ctx, int64_t B, const uint64_t *rows, const uint8_t *remaining, const uint8_t *item_wh,
+                             const int32_t *action, uint64_t *rows_out, uint8_t *remaining_out, int32_t *status_out) {
+    if (!ctx || B < 0 || !rows || !remaining || !item_wh || !action || !rows_out || !remaining_out || !status_out)
+        return fail(ctx, RP_ERR_ARG, "rp_apply_move: bad argument");
+    if (B == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    u64 *drows = s.up((const u64 *)rows, (size_t)B * d.H); NEED(drows);
+    u8 *drem = s.up(remaining, (size_t)B * d.N); NEED(drem);
+    u8 *dwh = s.up(item_wh, (size_t)B * d.N * 2); NEED(dwh);
+    int *dact = s.up(action, (size_t)B); NEED(dact);
+    u64 *drows_o = s.up((const u64 *)nullptr, (size_t)B * d.H); NEED(drows_o);
+    u8 *drem_o = s.up((const u8 *)nullptr, (size_t)B * d.N); NEED(drem_o);
+    int *dst = s.up((const int *)nullptr, (size_t)B); NEED(dst);
+    DISPATCH(ctx, k_apply_move, grid_for(B), d, (long long)B, drows, drem, dwh, dact, drows_o, drem_o, dst);
+    HIPCHK(ctx, hipMemcpyAsync(rows_out, drows_o, (size_t)B * d.H * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(remaining_out, drem_o, (size_t)B * d.N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(status_out, dst, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+// sorted[int(floor(len*alpha)) - 1] with Python's negative-index wrap (BinPackingGame.py:205-206)
+static bool rank_threshold(const double *rewards, int n, double alpha, double *bl) {
+    if (n <= 0) return false;
+    std::vector<double> s(rewards, rewards + n);
+    std::sort(s.begin(), s.end());
+    int idx = (int)floor((double)n * alpha) - 1;
+    if (idx < 0) idx += n;
+    if (idx >= n) idx = n - 1;
+    *bl = s[idx];
+    return true;
+}
+
+extern "C" int rp_game_ended(rp_ctx *ctx, int64_t B, const uint64_t *rows, const uint8_t *remaining, const uint8_t *item_wh,
+                             const int32_t *total_area, const int32_t *max_h, const double *rewards, int32_t n_rewards, double alpha,
+                             int32_t *ended_out, double *reward_out) {
+    if (!ctx || B < 0 || !rows || !remaining || !item_wh || !total_area || !max_h || !ended_out || !reward_out || n_rewards < 0 ||
+        (n_rewards > 0 && !rewards))
+        return fail(ctx, RP_ERR_ARG, "rp_game_ended: bad argument");
+    if (B == 0) return RP_OK;
+    const DP &d = ctx->d;
+    double bl = 0.0;
+    bool has = rank_threshold(rewards, n_rewards, alpha, &bl);
+    Scratch s(ctx);
+    u64 *drows = s.up((const u64 *)rows, (size_t)B * d.H); NEED(drows);
+    u8 *drem = s.up(remaining, (size_t)B * d.N); NEED(drem);
+    u8 *dwh = s.up(item_wh, (size_t)B * d.N * 2); NEED(dwh);
+    int *darea = s.up(total_area, (size_t)B); NEED(darea);
+    int *dmh = s.up(max_h, (size_t)B); NEED(dmh);
+    int *dend = s.up((const int *)nullptr, (size_t)B); NEED(dend);
+    double *drew = s.up((const double *)nullptr, (size_t)B); NEED(drew);
+    DISPATCH(ctx, k_game_ended, grid_for(B), d, (long long)B, drows, drem, dwh, darea, dmh, has ? 1 : 0, bl, dend, drew);
+    HIPCHK(ctx, hipMemcpyAsync(ended_out, dend, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(reward_out, drew, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n) {
+    if (!ctx || n < 0 || (n > 0 && !rewards)) return fail(ctx, RP_ERR_ARG, "rp_set_rank_buffer: bad argument");
+    double bl = 0.0;
+    int has = rank_threshold(rewards, n, ctx->cfg.alpha, &bl) ? 1 : 0;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d.g_bl, &bl, sizeof bl, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d.g_has_buf, &has, sizeof has, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_begin_episodes(rp_ctx *ctx, int32_t first, int32_t count, const uint8_t *item_wh, const int32_t *total_area,
+                                 const uint64_t *episode_id) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G || !item_wh || !total_area)
+        return fail(ctx, RP_ERR_ARG, "rp_begin_episodes: bad argument");
+    if (count == 0) return RP_OK;
+    const DP &d = ctx->d;
+    std::vector<int> mh(count, 0);
+    std::vector<u64> ids(count);
+    for (int k = 0; k < count; ++k) {
+        for (int i = 0; i < d.N; ++i) {
+            int w = item_wh[((size_t)k * d.N + i) * 2], h = item_wh[((size_t)k * d.N + i) * 2 + 1];
+            if (w < 1 || w > d.W || h < 1 || h > d.H) return fail(ctx, RP_ERR_ARG, "item %d of episode %d has size %dx%d outside the %dx%d grid", i, k, w, h, d.W, d.H);
+            mh[k] = std::max(mh[k], h);  // BinPackingGame.getInitItems: max_h over ALL items (BinPackingGame.py:41-50)
+        }
+        ids[k] = episode_id ? episode_id[k] : (u64)(first + k);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d.item_wh + (size_t)first * d.N * 2, item_wh, (size_t)count * d.N * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d.total_area + first, total_area, (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d.max_h + first, mh.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d.episode + first, ids.data(), (size_t)count * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)nullptr, (const u8 *)nullptr, 1);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uint64_t *rows, const uint8_t *remaining) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G || !rows || !remaining) return fail(ctx, RP_ERR_ARG, "rp_set_roots: bad argument");
+    if (count == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    u64 *drows = s.up((const u64 *)rows, (size_t)count * d.H); NEED(drows);
+    u8 *drem = s.up(remaining, (size_t)count * d.N); NEED(drem);
+    DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)drows, (const u8 *)drem, 0);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
+    if (!ctx) return RP_ERR_ARG;
+    const DP &d = ctx->d;
+    HIPCHK(ctx, hipMemsetAsync(d.eval_count, 0, sizeof(int), ctx->stream));
+    DISPATCH(ctx, k_search, grid_for(d.G), d);
+    if (n_leaves_out) {
+        int n = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        int rc = check_device_error(ctx);  // synchronises
+        if (rc != RP_OK) return rc;
+        *n_leaves_out = n;
+    }
+    return RP_OK;
+}
+
+extern "C" int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows) {
+    if (!ctx || !planes_dev || capacity_rows < 0) return fail(ctx, RP_ERR_ARG, "rp_leaf_planes: bad argument");
+    const DP &d = ctx->d;
+    long long rows = std::min<long long>(capacity_rows, d.G);
+    if (rows == 0) return RP_OK;
+    DISPATCH(ctx, k_leaf_planes, grid_for(rows), d, planes_dev, (long long)capacity_rows);
+    return RP_OK;
+}
+
+extern "C" int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out, uint8_t *remaining_out, int32_t *slot_out, int32_t *n_out) {
+    if (!ctx || max_rows < 0 || !rows_out || !remaining_out || !slot_out || !n_out) return fail(ctx, RP_ERR_ARG, "rp_leaf_states: bad argument");
+    const DP &d = ctx->d;
+    int n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    n = std::min(n, (int)max_rows);
+    *n_out = n;
+    if (n == 0) return RP_OK;
+    Scratch s(ctx);
+    u64 *drows = s.up((const u64 *)nullptr, (size_t)n * d.H); NEED(drows);
+    u8 *drem = s.up((const u8 *)nullptr, (size_t)n * d.N); NEED(drem);
+    int *dslot = s.up((const int *)nullptr, (size_t)n); NEED(dslot);
+    DISPATCH(ctx, k_leaf_states, grid_for(n), d, drows, drem, dslot, n);
+    HIPCHK(ctx, hipMemcpyAsync(rows_out, drows, (size_t)n * d.H * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(remaining_out, drem, (size_t)n * d.N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(slot_out, dslot, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev) {
+    if (!ctx || !pi_dev || !v_dev) return fail(ctx, RP_ERR_ARG, "rp_commit_eval: bad argument");
+    const DP &d = ctx->d;
+    DISPATCH(ctx, k_commit, grid_for(d.G), d, pi_dev, v_dev);
+    return RP_OK;
+}
+
+extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows) {
+    if (!ctx || !pi_host || !v_host || n_rows < 0) return fail(ctx, RP_ERR_ARG, "rp_commit_eval_host: bad argument");
+    const DP &d = ctx->d;
+    int n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_rows < n) return fail(ctx, RP_ERR_ARG, "rp_commit_eval_host: %d rows given, %d leaves waiting", n_rows, n);
+    if (n == 0) return RP_OK;
+    Scratch s(ctx);
+    float *dpi = s.up(pi_host, (size_t)n * d.A); NEED(dpi);
+    float *dv = s.up(v_host, (size_t)n); NEED(dv);
+    DISPATCH(ctx, k_commit, grid_for(n), d, (const float *)dpi, (const float *)dv);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_root_counts(rp_ctx *ctx, int32_t first, int32_t count, uint32_t *counts_out) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G || !counts_out) return fail(ctx, RP_ERR_ARG, "rp_root_counts: bad argument");
+    if (count == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    u32 *dc = s.up((const u32 *)nullptr, (size_t)count * d.A); NEED(dc);
+    hipLaunchKernelGGL(k_root_counts, dim3(grid_for(count)), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, (int)first, (int)count, dc);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(counts_out, dc, (size_t)count * d.A * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_game_status(rp_ctx *ctx, int32_t first, int32_t count, int32_t *phase_out, int32_t *sims_done_out, int32_t *moves_out,
+                              uint64_t *episode_out) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G) return fail(ctx, RP_ERR_ARG, "rp_game_status: bad argument");
+    const DP &d = ctx->d;
+    if (phase_out) HIPCHK(ctx, hipMemcpyAsync(phase_out, d.phase + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (sims_done_out) HIPCHK(ctx, hipMemcpyAsync(sims_done_out, d.sims_done + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (moves_out) HIPCHK(ctx, hipMemcpyAsync(moves_out, d.moves + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (episode_out) HIPCHK(ctx, hipMemcpyAsync(episode_out, d.episode + first, (size_t)count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_advance_roots(rp_ctx *ctx, int32_t first, int32_t count, const int32_t *action, int32_t *ended_out, double *score_out) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G || !action) return fail(ctx, RP_ERR_ARG, "rp_advance_roots: bad argument");
+    if (count == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    int *dact = s.up(action, (size_t)count); NEED(dact);
+    DISPATCH(ctx, k_advance, grid_for(count), d, (int)first, (int)count, (const int *)dact);
+    if (ended_out) HIPCHK(ctx, hipMemcpyAsync(ended_out, d.last_outcome + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (score_out) HIPCHK(ctx, hipMemcpyAsync(score_out, d.last_score + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_pop_finished(rp_ctx *ctx, int64_t max_n, uint64_t *episode_id_out, int32_t *outcome_out, double *score_out,
+                               int32_t *moves_out, int64_t *n_out) {
+    if (!ctx || max_n < 0 || !n_out) return fail(ctx, RP_ERR_ARG, "rp_pop_finished: bad argument");
+    const DP &d = ctx->d;
+    int cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&cnt, d.fin_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    cnt = std::min(cnt, d.fin_cap);
+    int64_t avail = cnt - ctx->fin_popped, n = std::min(avail, max_n);
+    *n_out = n;
+    if (n <= 0) { *n_out = 0; return RP_OK; }
+    size_t off = (size_t)ctx->fin_popped;
+    if (episode_id_out) HIPCHK(ctx, hipMemcpyAsync(episode_id_out, d.fin_episode + off, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (outcome_out) HIPCHK(ctx, hipMemcpyAsync(outcome_out, d.fin_outcome + off, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (score_out) HIPCHK(ctx, hipMemcpyAsync(score_out, d.fin_score + off, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (moves_out) HIPCHK(ctx, hipMemcpyAsync(moves_out, d.fin_moves + off, n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->fin_popped += n;
+    if (ctx->fin_popped == cnt) {  // ring drained: rewind
+        HIPCHK(ctx, hipMemsetAsync(d.fin_count, 0, sizeof(int), ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fin_popped = 0;
+    }
+    return RP_OK;
+}
+
+extern "C" int rp_set_instance_pool(rp_ctx *ctx, int64_t n_instances, const uint8_t *item_wh, const int32_t *total_area, uint64_t first_id) {
+    if (!ctx || n_instances < 0 || (n_instances > 0 && (!item_wh || !total_area))) return fail(ctx, RP_ERR_ARG, "rp_set_instance_pool: bad argument");
+    DP &d = ctx->d;
+    std::vector<int> mh((size_t)n_instances, 0);
+    for (int64_t k = 0; k < n_instances; ++k)
+        for (int i = 0; i < d.N; ++i) {
+            int w = item_wh[((size_t)k * d.N + i) * 2], h = item_wh[((size_t)k * d.N + i) * 2 + 1];
+            if (w < 1 || w > d.W || h < 1 || h > d.H) return fail(ctx, RP_ERR_ARG, "item %d of instance %lld has size %dx%d outside the %dx%d grid", i, (long long)k, w, h, d.W, d.H);
+            mh[k] = std::max(mh[k], h);
+        }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_instances > ctx->pool_cap) {  // grow (old buffers stay in ctx->allocs until destroy)
+        ALLOC(ctx, ctx->pool_wh, (size_t)n_instances * d.N * 2);
+        ALLOC(ctx, ctx->pool_area, (size_t)n_instances);
+        ALLOC(ctx, ctx->pool_max_h, (size_t)n_instances);
+        ctx->pool_cap = n_instances;
+    }
+    if (n_instances > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pool_wh, item_wh, (size_t)n_instances * d.N * 2, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pool_area, total_area, (size_t)n_instances * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pool_max_h, mh.data(), (size_t)n_instances * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemsetAsync(d.next_instance, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    d.pool_wh = ctx->pool_wh; d.pool_area = ctx->pool_area; d.pool_max_h = ctx->pool_max_h;
+    d.n_instances = n_instances; d.first_id = first_id;
+    return RP_OK;
+}
+
+extern "C" int rp_begin_pool(rp_ctx *ctx) {
+    if (!ctx) return RP_ERR_ARG;
+    const DP &d = ctx->d;
+    if (!d.pool_wh) return fail(ctx, RP_ERR_STATE, "rp_begin_pool: no instance pool set");
+    DISPATCH(ctx, k_pool_begin, grid_for(d.G), d);
+    return check_device_error(ctx);
+}
+
+extern "C" int rp_examples_count(rp_ctx *ctx, int64_t *n_out) {
+    if (!ctx || !n_out) return fail(ctx, RP_ERR_ARG, "rp_examples_count: bad argument");
+    unsigned long long n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d.ex_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = std::min<int64_t>((int64_t)n, ctx->d.max_examples);
+    return RP_OK;
+}
+
+extern "C" int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes_dev, float *pi_dev, float *value_dev) {
+    if (!ctx || first < 0 || count < 0 || !planes_dev || !pi_dev || !value_dev) return fail(ctx, RP_ERR_ARG, "rp_examples_tensors: bad argument");
+    int64_t n = 0;
+    int rc = rp_examples_count(ctx, &n);
+    if (rc != RP_OK) return rc;
+    if (first + count > n) return fail(ctx, RP_ERR_ARG, "rp_examples_tensors: range [%lld,%lld) exceeds the %lld recorded examples", (long long)first, (long long)(first + count), (long long)n);
+    if (count == 0) return RP_OK;
+    const DP &d = ctx->d;
+    DISPATCH(ctx, k_examples, grid_for(count), d, (long long)first, (long long)count, planes_dev, pi_dev, value_dev);
+    return RP_OK;
+}
+
+extern "C" int rp_examples_clear(rp_ctx *ctx) {
+    if (!ctx) return RP_ERR_ARG;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d.ex_count, 0, sizeof(unsigned long long), ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_counters(rp_ctx *ctx, int64_t *out12, int32_t reset) {
+    if (!ctx || !out12) return fail(ctx, RP_ERR_ARG, "rp_counters: bad argument");
+    HIPCHK(ctx, hipMemcpyAsync(out12, ctx->d.counters, CNT_N * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d.counters, 0, CNT_N * sizeof(u64), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out) {
+    if (!ctx || slot < 0 || slot >= ctx->d.G || !n_nodes_out || !n_edges_out) return fail(ctx, RP_ERR_ARG, "rp_tree_size: bad argument");
+    HIPCHK(ctx, hipMemcpyAsync(n_nodes_out, ctx->d.n_nodes + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(n_edges_out, ctx->d.n_edges + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint8_t *node_remaining, int8_t *node_term, uint8_t *node_term_kind,
+                            uint8_t *node_expanded, uint32_t *node_ns, uint32_t *node_edge_off, uint32_t *node_n_valid, uint16_t *edge_action,
+                            double *edge_p, double *edge_q, uint32_t *edge_nsa, uint8_t *edge_q_kind, uint32_t *edge_child) {
+    if (!ctx || slot < 0 || slot >= ctx->d.G) return fail(ctx, RP_ERR_ARG, "rp_dump_tree: bad argument");
+    const DP &d = ctx->d;
+    int nn = 0, ne = 0;
+    int rc = rp_tree_size(ctx, slot, &nn, &ne);
+    if (rc != RP_OK) return rc;
+    std::vector<NodeHdr> hdr(nn);
+    std::vector<u32> key((size_t)nn * d.KW), eN(ne), eC(ne);
+    HIPCHK(ctx, hipMemcpy(hdr.data(), d.hdr + (size_t)slot * d.node_cap, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(key.data(), d.key + (size_t)slot * d.node_cap * d.KW, (size_t)nn * d.KW * 4, hipMemcpyDeviceToHost));
+    size_t eb = (size_t)slot * d.edge_cap;
+    HIPCHK(ctx, hipMemcpy(edge_action, d.eAct + eb, (size_t)ne * 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(edge_p, d.eP + eb, (size_t)ne * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(edge_q, d.eQ + eb, (size_t)ne * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(eN.data(), d.eN + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(edge_child, d.eChild + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < ne; ++e) { edge_nsa[e] = eN[e] & NSA_MASK; edge_q_kind[e] = (u8)(eN[e] >> 30); }
+    for (int i = 0; i < nn; ++i) {
+        const u32 *k = key.data() + (size_t)i * d.KW;
+        for (int r = 0; r < d.H; ++r) node_rows[(size_t)i * d.H + r] = ctx->row64 ? ((const u64 *)k)[r] : (u64)k[r];
+        const u32 *rw = k + d.H * d.RW;
+        for (int it = 0; it < d.N; ++it) node_remaining[(size_t)i * d.N + it] = (u8)((rw[it >> 5] >> (it & 31)) & 1u);
+        node_term[i] = hdr[i].term; node_term_kind[i] = hdr[i].term_kind; node_expanded[i] = hdr[i].expanded;
+        node_ns[i] = hdr[i].ns; node_edge_off[i] = hdr[i].edge_off; node_n_valid[i] = hdr[i].n_valid;
+    }
+    return RP_OK;
+}
+
+extern "C" int rp_selftest_sqrt(rp_ctx *ctx, int64_t n, double *sqrt_n_out, double *sqrt_n_eps_out) {
+    if (!ctx || n < 0 || !sqrt_n_out || !sqrt_n_eps_out) return fail(ctx, RP_ERR_ARG, "rp_selftest_sqrt: bad argument");
+    if (n == 0) return RP_OK;
+    Scratch s(ctx);
+    double *a = s.up((const double *)nullptr, (size_t)n); NEED(a);
+    double *b = s.up((const double *)nullptr, (size_t)n); NEED(b);
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, a, b);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(sqrt_n_out, a, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(sqrt_n_eps_out, b, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_selftest_q_update(rp_ctx *ctx, int64_t n, const double *q, const uint8_t *q_kind, const uint32_t *nsa, const double *v,
+                                    const uint8_t *v_kind, double *q_out, uint8_t *q_kind_out) {
+    if (!ctx || n < 0 || !q || !q_kind || !nsa || !v || !v_kind || !q_out || !q_kind_out) return fail(ctx, RP_ERR_ARG, "rp_selftest_q_update: bad argument");
+    if (n == 0) return RP_OK;
+    Scratch s(ctx);
+    double *dq = s.up(q, (size_t)n); NEED(dq);
+    u8 *dqk = s.up(q_kind, (size_t)n); NEED(dqk);
+    u32 *dn = s.up(nsa, (size_t)n); NEED(dn);
+    double *dv = s.up(v, (size_t)n); NEED(dv);
+    u8 *dvk = s.up(v_kind, (size_t)n); NEED(dvk);
+    double *dqo = s.up((const double *)nullptr, (size_t)n); NEED(dqo);
+    u8 *dqko = s.up((const u8 *)nullptr, (size_t)n); NEED(dqko);
+    hipLaunchKernelGGL(k_selftest_q, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, dq, dqk, dn, dv, dvk, dqo, dqko);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(q_out, dqo, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q_kind_out, dqko, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}
+
+extern "C" int rp_selftest_masked_prior(rp_ctx *ctx, int64_t B, const float *pi, const uint8_t *valid, double *p_out) {
+    if (!ctx || B < 0 || !pi || !valid || !p_out) return fail(ctx, RP_ERR_ARG, "rp_selftest_masked_prior: bad argument");
+    if (B == 0) return RP_OK;
+    const DP &d = ctx->d;
+    Scratch s(ctx);
+    float *dpi = s.up(pi, (size_t)B * d.A); NEED(dpi);
+    u8 *dva = s.up(valid, (size_t)B * d.A); NEED(dva);
+    double *dout = s.up((const double *)nullptr, (size_t)B * d.A); NEED(dout);
+    u16 *dact = s.up((const u16 *)nullptr, (size_t)B * d.A); NEED(dact);
+    hipLaunchKernelGGL(k_selftest_prior, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, (long long)B, (const float *)dpi,
+                       (const u8 *)dva, dout, dact);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(p_out, dout, (size_t)B * d.A * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
+}

@@ -1,0 +1,189 @@
+"""GPU parity: the HIP tree search through the C ABI against (a) golden episodes captured from the
+reference's MCTS_bpp.MCTS and (b) the CPU oracle on freshly generated games.  Everything is compared
+bit for bit: visit counts per move, chosen placements, every node's Ns / Es and every edge's P, Nsa, Q."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import evaluators as ev
+import oracle_lib as orc
+from engine_util import assert_trees_equal, fixture_tree, host_evaluator, planes_from_state, run_until_idle, tree_as_dict
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MCTS_FILES = sorted(glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
+
+
+def make_engine(*a, **kw):
+    from resource_packing_self_play_amd._lib import Engine
+    return Engine(*a, **kw)
+
+
+@pytest.mark.parametrize("path", MCTS_FILES, ids=[os.path.basename(p)[5:-4] for p in MCTS_FILES])
+def test_episode_matches_reference_golden(path):
+    from resource_packing_self_play_amd import _lib
+    d = np.load(path)
+    W, H, N, sims = int(d["W"]), int(d["H"]), int(d["N"]), int(d["sims"])
+    kind, salt = str(d["kind"]), int(d["salt"])
+    eng = make_engine(W, H, N, 1, sims, cpuct=float(d["cpuct"]), alpha=float(d["alpha"]), move_rule=_lib.MOVE_EXTERNAL, tie_salt=salt)
+    eng.set_rank_buffer(d["buf"])
+    wh = np.stack([d["item_w"], d["item_h"]], axis=1)[None]
+    eng.begin_episodes(wh, [int(d["total_area"])])
+    evaluate = host_evaluator(lambda s: kind, W * N, lambda s: salt)
+    evals = 0
+    for mv, action in enumerate(d["actions"]):
+        evals += run_until_idle(eng, evaluate)
+        ph, sd, moves, _ = eng.status()
+        assert ph[0] == _lib.PHASE_MOVE_READY and sd[0] == sims and moves[0] == mv
+        counts = eng.root_counts()[0]
+        assert np.array_equal(counts, d["counts"][mv]), "visit counts differ at move %d" % mv
+        ended, score = eng.advance_roots([int(action)])
+        if mv + 1 < len(d["actions"]):
+            assert ended[0] == 0
+    assert ended[0] == int(d["outcome"]) and score[0] == float(d["score"])
+    assert evals == int(d["evals"])
+    assert_trees_equal(tree_as_dict(eng.dump_tree(0)), fixture_tree(d), os.path.basename(path))
+    c = eng.counters()
+    assert c["expansions"] == int(d["evals"]) and c["simulations"] == sims * len(d["actions"])
+    eng.close()
+
+
+CASES = [  # W, H, N, sims, games, kind, rule
+    (10, 10, 8, 50, 48, "hashed", "argmax"),
+    (10, 10, 8, 64, 40, "sparse", "sample"),
+    (10, 10, 8, 30, 32, "peaked", "sample"),
+    (20, 20, 32, 24, 12, "hashed", "sample"),
+    (15, 15, 10, 40, 16, "uniform", "argmax"),
+    (33, 12, 9, 30, 8, "hashed", "sample"),  # 64-bit rows
+    (50, 50, 128, 10, 3, "peaked", "argmax"),
+]
+
+
+def gen_items(rng, W, H, N):
+    """guillotine split of the W x H rectangle into N items, like ItemsGenerator (BinPackingGame.py:257-285)."""
+    items = [(W, H)]
+    while len(items) < N:
+        k = int(rng.integers(len(items))); w, h = items[k]
+        if rng.integers(2) == 0:
+            if w == 1: continue
+            c = int(rng.integers(1, w)); items.pop(k); items += [(c, h), (w - c, h)]
+        else:
+            if h == 1: continue
+            c = int(rng.integers(1, h)); items.pop(k); items += [(w, c), (w, h - c)]
+    return np.array(items, np.uint8)
+
+
+@pytest.mark.parametrize("W,H,N,sims,games,kind,rule", CASES)
+def test_self_play_matches_oracle(W, H, N, sims, games, kind, rule):
+    """Whole episodes with the engine's own move rules (auto moves on device) vs the oracle playing the
+    same instances: every action, outcome, score, and the complete final tree of every game."""
+    from resource_packing_self_play_amd import _lib
+    rng = np.random.default_rng(W * 7 + N + sims)
+    A = W * N
+    seed, salt = 1234 + sims, 99
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+    area = np.full(games, W * H, np.int32)
+    ratios = [a / b for a in range(1, H + 1) for b in range(a, H + 1)]
+    buf = rng.choice(ratios, size=60)
+    move_rule = _lib.MOVE_ARGMAX_FIRST if rule == "argmax" else _lib.MOVE_SAMPLE
+    eng = make_engine(W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=move_rule, seed=seed, tie_salt=salt)
+    eng.set_rank_buffer(buf)
+    eng.begin_episodes(wh, area, episode_id=np.arange(games) + 1000)
+    evaluate = host_evaluator(lambda s: kind, A, lambda s: salt)
+    run_until_idle(eng, evaluate)
+    ph, _, moves, _ = eng.status()
+    assert (ph == _lib.PHASE_EPISODE_DONE).all()
+    ids, outcome, score, nmoves = eng.pop_finished()
+    fin = {int(i): (int(o), float(s), int(m)) for i, o, s, m in zip(ids, outcome, score, nmoves)}
+    assert len(fin) == games
+    stats = dict.fromkeys(("expansions", "searches", "terminal_returns", "path_edges", "sum_valid_select", "sum_valid_leaf", "transposition_hits", "nodes"), 0)
+    for g in range(games):
+        m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: ev.table_eval(kind, ev.pack_board(b), r, A, salt),
+                           lambda b, r: ev.tie_value(ev.pack_board(b), r, salt))
+        m.begin_episode(wh[g, :, 0], wh[g, :, 1], W * H, buf)
+        actions, _, o, s = m.play_episode(sims, policy=0 if rule == "argmax" else 1, seed=seed, episode_id=1000 + g, want_counts=False)
+        assert fin[1000 + g] == (o, s, len(actions)), g
+        assert moves[g] == len(actions)
+        assert_trees_equal(tree_as_dict(eng.dump_tree(g)), m.dump(), "game %d" % g)
+        for k, v in m.stats().items():
+            stats[k] += v
+        m.close()
+    c = eng.counters()
+    assert c["simulations"] == stats["searches"] and c["expansions"] == stats["expansions"]
+    assert c["terminal_returns"] == stats["terminal_returns"] and c["path_edges"] == stats["path_edges"]
+    assert c["sum_valid_select"] == stats["sum_valid_select"] and c["sum_valid_leaf"] == stats["sum_valid_leaf"]
+    assert c["nodes"] == stats["nodes"] and c["transposition_links"] == stats["transposition_hits"]
+    assert c["episodes"] == games
+    eng.close()
+
+
+def test_set_roots_keeps_the_tree_like_getActionProb():
+    """MCTS.getActionProb on successive states of one MCTS object (CoachBPP.py:74-78): the engine is re-rooted with
+    rp_set_roots and must give the same counts as the oracle whose dicts persist."""
+    from resource_packing_self_play_amd import _lib
+    W, H, N, sims = 10, 10, 8, 40
+    A = W * N
+    rng = np.random.default_rng(5)
+    wh = gen_items(rng, W, H, N)
+    eng = make_engine(W, H, N, 1, sims, move_rule=_lib.MOVE_EXTERNAL, tie_salt=3)
+    eng.set_rank_buffer([0.9, 0.8, 1.0])
+    eng.begin_episodes(wh[None], [W * H])
+    m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: ev.table_eval("hashed", ev.pack_board(b), r, A, 3), lambda b, r: ev.tie_value(ev.pack_board(b), r, 3))
+    m.begin_episode(wh[:, 0], wh[:, 1], W * H, [0.9, 0.8, 1.0])
+    evaluate = host_evaluator(lambda s: "hashed", A, lambda s: 3)
+    board = np.zeros((H, W), np.uint8); rem = np.ones(N, np.uint8)
+    for step in range(5):
+        eng.set_roots(ev.pack_board(board)[None], rem[None])
+        run_until_idle(eng, evaluate)
+        counts = eng.root_counts()[0]
+        want = m.action_counts(board, rem, sims)
+        assert np.array_equal(counts, want), step
+        valid, n = orc.valid_moves(W, H, N, board, wh[:, 0], wh[:, 1], rem)
+        if n == 0:
+            break
+        a = int(rng.choice(np.nonzero(valid)[0]))  # any legal move, also one the search never visited
+        _, board, rem = orc.next_state(W, H, N, board, wh[:, 0], wh[:, 1], rem, a)
+    assert_trees_equal(tree_as_dict(eng.dump_tree(0)), m.dump())
+    eng.close(); m.close()
+
+
+def test_leaf_planes_match_getBinItem():
+    import torch
+    from resource_packing_self_play_amd import _lib
+    for (W, H, N) in [(10, 10, 8), (20, 20, 32), (33, 12, 9)]:
+        games, sims = 16, 6
+        rng = np.random.default_rng(N)
+        wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+        eng = make_engine(W, H, N, games, sims, move_rule=_lib.MOVE_ARGMAX_FIRST, stream=torch.cuda.current_stream().cuda_stream)
+        eng.begin_episodes(wh, np.full(games, W * H, np.int32))
+        evaluate = host_evaluator(lambda s: "hashed", W * N, lambda s: 0)
+        buf = torch.full((games, N + 1, H, W), -7.0, device="cuda")
+        for step in range(30):
+            n = eng.search_step()
+            if n == 0:
+                break
+            eng.leaf_planes(buf.data_ptr(), games)
+            rows, rem, slots = eng.leaf_states(n)
+            got = buf.cpu().numpy()
+            for b in range(n):
+                want = planes_from_state(rows[b], rem[b], wh[slots[b]], W, H)
+                assert np.array_equal(got[b], want), (W, step, b)
+            pi, v = evaluate(rows, rem, slots)
+            eng.commit_eval_host(pi, v)
+        eng.close()
+
+
+def test_capacity_overflow_is_reported():
+    from resource_packing_self_play_amd import _lib
+    W, H, N = 10, 10, 8
+    rng = np.random.default_rng(0)
+    wh = gen_items(rng, W, H, N)
+    eng = make_engine(W, H, N, 1, 50, move_rule=_lib.MOVE_ARGMAX_FIRST, node_cap=12)
+    eng.begin_episodes(wh[None], [W * H])
+    evaluate = host_evaluator(lambda s: "uniform", W * N, lambda s: 0)
+    with pytest.raises(_lib.EngineError) as ei:
+        run_until_idle(eng, evaluate)
+    assert ei.value.code == _lib.ERR_CAPACITY
+    eng.close()
