@@ -129,6 +129,10 @@ int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n);
 int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uint64_t *rows /*[count][H]*/,
                  const uint8_t *remaining /*[count][N]*/);
 
+/* Changes args.numMCTSSims for the following searches (MCTS_bpp.py:37); rp_search_step stops a slot after this many
+ * simulations from its current root. */
+int rp_set_sims(rp_ctx *ctx, int32_t sims);
+
 /* ---- search: MCTS.search (MCTS_bpp.py:56-139) in lock step over all slots ------------- */
 /* Runs simulations for every RUNNING slot until each either needs a leaf evaluated (the
  * nnet.predict call of MCTS_bpp.py:87) or has finished its args.numMCTSSims budget
@@ -157,6 +161,8 @@ int rp_root_counts(rp_ctx *ctx, int32_t first, int32_t count, uint32_t *counts_o
 /* phase_out / sims_done_out / moves_out / episode_out: host buffers [count] (any may be NULL) */
 int rp_game_status(rp_ctx *ctx, int32_t first, int32_t count, int32_t *phase_out, int32_t *sims_done_out,
                    int32_t *moves_out, uint64_t *episode_out);
+/* Return value of each slot's latest simulation (MCTS.search returns v, MCTS_bpp.py:83,104,139) and its kind. */
+int rp_last_values(rp_ctx *ctx, int32_t first, int32_t count, double *v_out, int32_t *kind_out);
 /* Plays `action[i]` in slot first+i (CoachBPP.py:88-91): the child becomes the root, the tree is
  * kept; ended_out[i] = 0 / +-1 as getGameEnded, score_out[i] = r.  Only with RP_MOVE_EXTERNAL. */
 int rp_advance_roots(rp_ctx *ctx, int32_t first, int32_t count, const int32_t *action, int32_t *ended_out,

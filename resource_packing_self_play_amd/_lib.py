@@ -50,6 +50,8 @@ _SIGS = {
     "rp_begin_pool": (C.c_int, [_vp]),
     "rp_set_rank_buffer": (C.c_int, [_vp, _vp, _i32]),
     "rp_set_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "rp_set_sims": (C.c_int, [_vp, _i32]),
+    "rp_last_values": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rp_search_step": (C.c_int, [_vp, _vp]),
     "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
     "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
@@ -181,6 +183,16 @@ class Engine:
         rows = _arr(rows, np.uint64); count = rows.shape[0]
         rows = _arr(rows, np.uint64, (count, self.H)); remaining = _arr(remaining, np.uint8, (count, self.N))
         self._ck(self.L.rp_set_roots(self.h, first, count, _ptr(rows), _ptr(remaining)))
+
+    def set_sims(self, sims):
+        self._ck(self.L.rp_set_sims(self.h, int(sims)))
+        self.sims = int(sims)
+
+    def last_values(self, first=0, count=None):
+        count = self.G - first if count is None else count
+        v = np.empty(count, np.float64); k = np.empty(count, np.int32)
+        self._ck(self.L.rp_last_values(self.h, first, count, _ptr(v), _ptr(k)))
+        return v, k
 
     # ---- search --------------------------------------------------------------------------
     def search_step(self, sync=True):

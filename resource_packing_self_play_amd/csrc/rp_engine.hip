@@ -76,6 +76,8 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *game_row;
     int *last_outcome;
     double *last_score;
+    double *last_v;     // value returned by the slot's latest simulation (MCTS.search's return value)
+    int *last_vkind;
     // evaluation queue
     int *eval_count, *eval_slot;
     // arenas
@@ -115,6 +117,8 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *fin_outcome, *fin_moves;
     double *fin_score;
 };
+// the first error of a launch sequence is the one reported (later ones are usually its consequences)
+__device__ __forceinline__ void set_error(const DP &p, int code) { atomicCAS(p.error, 0, code); }
 
 // ------------------------------------------------------------------------------------------------
 // wave helpers
@@ -394,7 +398,7 @@ template <typename row_t> struct Tree {
             if (first_empty < 64) { insert_slot = (slot + first_empty) & mask; return NONE32; }
             slot = (slot + 64) & mask;
         }
-        if (lane_id() == 0) atomicMax(p.error, ERR_TABLE_FULL);
+        if (lane_id() == 0) set_error(p, ERR_TABLE_FULL);
         insert_slot = NONE32;
         return NONE32;
     }
@@ -404,7 +408,7 @@ template <typename row_t> struct Tree {
     // terminal value.  Returns the node id or NONE32 on arena overflow.
     __device__ u32 materialize(row_t myrow, u64 rem0, u64 rem1, u64 h, u32 insert_slot) {
         if (n_nodes >= (u32)p.node_cap || insert_slot == NONE32) {
-            if (lane_id() == 0) atomicMax(p.error, ERR_NODE_CAP);
+            if (lane_id() == 0) set_error(p, ERR_NODE_CAP);
             return NONE32;
         }
         const u32 id = n_nodes;
@@ -414,7 +418,7 @@ template <typename row_t> struct Tree {
         sink.eChild = eChild + n_edges; sink.mask = nullptr; sink.cap = p.edge_cap - (int)n_edges;
         int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
         if (nv < 0) {
-            if (lane_id() == 0) atomicMax(p.error, ERR_EDGE_CAP);
+            if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
             return NONE32;
         }
         NodeHdr hd;
@@ -545,7 +549,7 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
         }
     }
     if (chosen == NONE32) {
-        if (lane == 0) { atomicMax(p.error, ERR_BAD_ACTION); p.phase[g] = RP_PHASE_FAILED; }
+        if (lane == 0) { set_error(p, ERR_BAD_ACTION); p.phase[g] = RP_PHASE_FAILED; }
         return;
     }
     u32 child = t.eChild[chosen];
@@ -572,7 +576,7 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
             for (u32 q = lane; q < hd.n_valid; q += 64) ec[t.eAct[hd.edge_off + q]] = t.eN[hd.edge_off + q] & NSA_MASK;
             if (lane == 0) { p.ex_value[idx] = 0; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
         } else if (lane == 0) {
-            atomicMax(p.error, ERR_EXAMPLES_CAP);
+            set_error(p, ERR_EXAMPLES_CAP);
         }
     }
     root = child;
@@ -599,7 +603,7 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
             if (idx < p.fin_cap) {
                 p.fin_episode[idx] = p.episode[g]; p.fin_outcome[idx] = ch.term; p.fin_score[idx] = r; p.fin_moves[idx] = moves;
             } else {
-                atomicMax(p.error, ERR_FINISHED_CAP);
+                set_error(p, ERR_FINISHED_CAP);
             }
         }
     } else if (lane == 0) {
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
             node = child;
         }
         if (failed) {
-            if (lane == 0) { atomicMax(p.error, ERR_PATH); }
+            if (lane == 0) { set_error(p, ERR_PATH); }
             phase = RP_PHASE_FAILED;
             break;
         }
@@ -728,6 +732,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
         }
         if (lane < depth) t.backup_entry(pn0, pe0, v, vkind);
         if (lane + 64 < depth) t.backup_entry(pn1, pe1, v, vkind);
+        if (lane == 0) { p.last_v[g] = v; p.last_vkind[g] = (int)vkind; }
         sims_done++;
         c[CNT_SIMS]++;
         wave_sync();
@@ -819,7 +824,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     u64 c[CNT_N];
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     c[CNT_SIMS] = 1; c[CNT_EXPAND] = 1; c[CNT_NVALID_LEAF] = hd.n_valid;
-    if (lane == 0) { p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; }
+    if (lane == 0) { p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32; }
     add_counters(p, c);
 }
 
@@ -1041,6 +1046,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long 
     if (lane_id() == 0) { ended[b] = e; reward[b] = r; }
 }
 
+__global__ void k_fill_rank(DP p, double bl, int has_buf) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < p.G) { p.bl[g] = bl; p.has_buf[g] = has_buf; }
+    if (g == 0) { *p.g_bl = bl; *p.g_has_buf = has_buf; }
+}
+
 // ---- device self-tests ----
 __global__ void k_selftest_sqrt(long long n, double *a, double *b) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1138,6 +1149,7 @@ static int check_device_error(rp_ctx *ctx) {
     HIPCHK(ctx, hipMemcpyAsync(&e, ctx->d.error, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (e == 0) return RP_OK;
+    (void)hipMemsetAsync(ctx->d.error, 0, sizeof(int), ctx->stream);
     static const char *names[] = {"", "node arena overflow (raise node_cap)", "edge arena overflow (raise edge_cap)",
                                   "transposition table full", "action is not a legal move of the root", "search path broken",
                                   "finished-episode ring overflow", "replay buffer full (raise max_examples)"};
@@ -1167,9 +1179,9 @@ extern "C" int64_t rp_device_bytes(const rp_ctx *ctx) { return ctx ? ctx->bytes 
 
 extern "C" void rp_destroy(rp_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->cfg.device);
-    hipStreamSynchronize(ctx->stream);
-    for (void *p : ctx->allocs) hipFree(p);
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs) (void)hipFree(p);
     delete ctx;
 }
 
@@ -1197,7 +1209,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.W = cfg->W; d.H = cfg->H; d.N = cfg->N; d.A = cfg->W * cfg->N; d.G = cfg->games; d.sims = cfg->sims;
     d.cpuct = cfg->cpuct; d.seed = cfg->seed; d.tie_salt = cfg->tie_salt; d.move_rule = cfg->move_rule;
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (cfg->N + 1) + 2;
-    d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 64) + d.A;
+    d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 96) + d.A;
     int tc = 64;
     while (tc < 2 * d.node_cap) tc *= 2;
     d.table_cap = tc;
@@ -1215,7 +1227,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.item_wh, G * N * 2); A_(d.total_area, G); A_(d.max_h, G); A_(d.bl, G); A_(d.has_buf, G);
     A_(d.root, G); A_(d.n_nodes, G); A_(d.n_edges, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
     A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
-    A_(d.last_outcome, G); A_(d.last_score, G);
+    A_(d.last_outcome, G); A_(d.last_score, G); A_(d.last_v, G); A_(d.last_vkind, G);
     A_(d.eval_count, 1); A_(d.eval_slot, G);
     A_(d.hdr, G * d.node_cap); A_(d.key, G * d.node_cap * d.KW);
     A_(d.eP, G * d.edge_cap); A_(d.eQ, G * d.edge_cap); A_(d.eN, G * d.edge_cap); A_(d.eChild, G * d.edge_cap); A_(d.eAct, G * d.edge_cap);
@@ -1237,7 +1249,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(plan, 2 * L + 2 * S + 4);
     if (rc != RP_OK) {
         std::string msg = ctx->err.empty() ? g_create_error : ctx->err;
-        for (void *p : ctx->allocs) hipFree(p);
+        for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, rc, "rp_create: %s (needs about %.1f GiB of HBM)", msg.c_str(),
                     (double)(G * ((size_t)d.node_cap * (16 + 4 * d.KW) + (size_t)d.edge_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
@@ -1249,7 +1261,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     hp.insert(hp.end(), sd.begin(), sd.end()); hp.insert(hp.end(), ss.begin(), ss.end());
     if (hipMemcpyAsync(plan, hp.data(), hp.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        for (void *p : ctx->allocs) hipFree(p);
+        for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, RP_ERR_DEVICE, "rp_create: plan upload failed");
     }
@@ -1270,7 +1282,7 @@ struct Scratch {
     rp_ctx *ctx;
     std::vector<void *> ptrs;
     explicit Scratch(rp_ctx *c) : ctx(c) {}
-    ~Scratch() { for (void *p : ptrs) hipFree(p); }
+    ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
     template <typename T> T *up(const T *host, size_t n) {
         void *p = nullptr;
         if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
@@ -1362,9 +1374,8 @@ extern "C" int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n)
     if (!ctx || n < 0 || (n > 0 && !rewards)) return fail(ctx, RP_ERR_ARG, "rp_set_rank_buffer: bad argument");
     double bl = 0.0;
     int has = rank_threshold(rewards, n, ctx->cfg.alpha, &bl) ? 1 : 0;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d.g_bl, &bl, sizeof bl, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d.g_has_buf, &has, sizeof has, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(k_fill_rank, dim3((ctx->d.G + 255) / 256), dim3(256), 0, ctx->stream, ctx->d, bl, has);
+    HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }
 
@@ -1403,6 +1414,21 @@ extern "C" int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uin
     DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)drows, (const u8 *)drem, 0);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_device_error(ctx);
+}
+
+extern "C" int rp_set_sims(rp_ctx *ctx, int32_t sims) {
+    if (!ctx || sims < 0 || (int64_t)sims * (ctx->d.N + 1) >= (int64_t)NSA_MASK) return fail(ctx, RP_ERR_ARG, "rp_set_sims: bad argument");
+    ctx->d.sims = sims;  // the device view is passed by value at every launch
+    ctx->cfg.sims = sims;
+    return RP_OK;
+}
+
+extern "C" int rp_last_values(rp_ctx *ctx, int32_t first, int32_t count, double *v_out, int32_t *kind_out) {
+    if (!ctx || first < 0 || count < 0 || first + count > ctx->d.G || !v_out) return fail(ctx, RP_ERR_ARG, "rp_last_values: bad argument");
+    HIPCHK(ctx, hipMemcpyAsync(v_out, ctx->d.last_v + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (kind_out) HIPCHK(ctx, hipMemcpyAsync(kind_out, ctx->d.last_vkind + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RP_OK;
 }
 
 extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {

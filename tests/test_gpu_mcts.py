@@ -88,7 +88,8 @@ def test_self_play_matches_oracle(W, H, N, sims, games, kind, rule):
     ratios = [a / b for a in range(1, H + 1) for b in range(a, H + 1)]
     buf = rng.choice(ratios, size=60)
     move_rule = _lib.MOVE_ARGMAX_FIRST if rule == "argmax" else _lib.MOVE_SAMPLE
-    eng = make_engine(W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=move_rule, seed=seed, tie_salt=salt)
+    eng = make_engine(W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=move_rule, seed=seed, tie_salt=salt,
+                      edge_cap=2_000_000 if W == 50 else 0)
     eng.set_rank_buffer(buf)
     eng.begin_episodes(wh, area, episode_id=np.arange(games) + 1000)
     evaluate = host_evaluator(lambda s: kind, A, lambda s: salt)
