@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Benchmark of the self-play hot path (BASELINE.json metric: MCTS node expansions/s + self-play episodes/s, 20x20 bin).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One STEP = one pass of the hot path over one batch of synthetic instances: a pool of `--pool` guillotine-split
+20x20 / 32-item instances (BASELINE.json configs[2]: 20x20 bin, 32 items, 400 MCTS sims per move) is played to the end
+through `--games` concurrent game slots per GPU (search kernels + FP32 CNN evaluator, inputs resident in HBM).  Every
+rank plays its own pool (weak scaling, no data-path collective); value = episodes all ranks finished / max-over-ranks time.
+
+The JSON line also carries
+  roofline        the dominant phase (the CNN evaluator, FP32 MFMA bound) from HIP-event timings taken inside the timed region
+  roofline_tree   the hand-written tree-walk kernels (k_search + k_commit, HBM bound): algorithmic bytes / event time
+  cpu_baseline    the C oracle (oracle/rp_oracle.c) + the same CNN through PyTorch CPU, batch 1 per leaf as the
+                  reference does, on a bounded sample of the same workload, rank 0 only
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward
+    "c1": (10, 10, 8, 25, 2.18e6),
+    "c2": (10, 10, 8, 100, 2.18e6),
+    "c3": (20, 20, 32, 400, 10.01e6),
+    "c4": (20, 20, 32, 100, 10.01e6),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
+
+
+def make_instances(W, H, N, count, base_seed):
+    """Guillotine splits of the W x H rectangle (h_gen = H, the hardest case: a perfect packing exists), one per
+    generator seed base_seed + index, through the package's ItemsGenerator."""
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    gen = ItemsGenerator(W, H, N)
+    state = np.random.get_state()
+    wh = np.array([[it[:2] for it in gen.items_generator(base_seed + k)] for k in range(count)], dtype=np.uint8)
+    np.random.set_state(state)
+    return wh
+
+
+def rank_buffer():
+    return np.random.RandomState(12345).uniform(0.8, 1.0, 100)
+
+
+class Args(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline worker (separate process, never touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_worker(cfg, episodes, seed0, budget_s):
+    import torch
+    torch.set_num_threads(1)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    from resource_packing_self_play_amd.binpacking.pytorch.BinpackingNNet import BinPackingNNet
+    W, H, N, sims, _ = CONFIGS[cfg]
+
+    class G:
+        def getBoardSize(self): return (H, W)
+        def getActionSize(self): return W * N
+    torch.manual_seed(0)
+    net = BinPackingNNet(G(), Args(num_items=N, num_bins=1)).eval()
+    wh_all = make_instances(W, H, N, episodes, seed0)
+    planes = np.zeros((1, N + 1, H, W), np.float32)
+    cur = {}
+
+    def evaluate(board, rem):  # NNetWrapper.predict on CPU, batch 1 (NNet.py:69-85)
+        planes[0, 0] = board
+        wh = cur["wh"]
+        for i in range(N):
+            planes[0, i + 1] = 0
+            if rem[i]:
+                planes[0, i + 1, :wh[i, 1], :wh[i, 0]] = 1
+        with torch.no_grad():
+            lp, v = net(torch.from_numpy(planes))
+        return torch.exp(lp)[0].numpy(), v[0].numpy()
+
+    m = orc.OracleMCTS(W, H, N, 1.0, 0.75, evaluate, None)
+    buf = rank_buffer()
+    t0 = time.time(); done = 0; expansions = 0; searches = 0
+    for k in range(episodes):
+        cur["wh"] = wh_all[k]
+        m.begin_episode(wh_all[k, :, 0], wh_all[k, :, 1], W * H, buf)
+        m.play_episode(sims, policy=1, seed=1, episode_id=k, want_counts=False)
+        st = m.stats()
+        done += 1; expansions += st["expansions"]; searches += st["searches"]
+        if time.time() - t0 > budget_s:
+            break
+    print(json.dumps({"episodes": done, "seconds": time.time() - t0, "expansions": expansions, "simulations": searches}))
+
+
+def run_cpu_baseline(cfg, budget_s):
+    """Spawns one single-threaded worker per host core available to this process; each plays whole episodes of the bench
+    workload for about `budget_s` seconds.  Returns the cpu_baseline object."""
+    cores = len(os.sched_getaffinity(0))
+    workers = max(1, min(cores, 32))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg, "--cpu-episodes", "64",
+                               "--cpu-seed", str(100 + 1000 * w), "--cpu-budget", str(budget_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+             for w in range(workers)]
+    outs = []
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pass
+    if not outs:
+        return None
+    wall = max(o["seconds"] for o in outs)
+    eps = sum(o["episodes"] for o in outs)
+    exp = sum(o["expansions"] for o in outs)
+    W, H, N, sims, _ = CONFIGS[cfg]
+    return {"value": eps / wall, "unit": "episodes/s", "cores": len(outs), "kind": "port",
+            "expansions_per_s": exp / wall, "per_core_episodes_per_s": eps / wall / len(outs),
+            "sample": "%d whole episodes of the bench workload (%dx%d, %d items, %d sims/move, seeds 100+), C oracle search + "
+                      "the same CNN via PyTorch CPU at batch 1 per leaf, one single-threaded process per core, %.1f s wall"
+                      % (eps, W, H, N, sims, wall)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--games", type=int, default=4096, help="concurrent game slots per GPU")
+    ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default 2 x games)")
+    ap.add_argument("--sims", type=int, default=0)
+    ap.add_argument("--edge-factor", type=int, default=72, help="edge arena = node arena x this")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--event-every", type=int, default=16, help="take per-phase HIP-event timings every n-th wave")
+    ap.add_argument("--cpu-worker", default=None)
+    ap.add_argument("--cpu-episodes", type=int, default=1)
+    ap.add_argument("--cpu-seed", type=int, default=100)
+    a = ap.parse_args()
+    if a.cpu_worker:
+        return cpu_worker(a.cpu_worker, a.cpu_episodes, a.cpu_seed, a.cpu_budget)
+
+    W, H, N, sims, flops_leaf = CONFIGS[a.config]
+    sims = a.sims or sims
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_base = None
+    if rank == 0 and not a.no_cpu_baseline:  # before this process touches the GPU
+        cpu_base = run_cpu_baseline(a.config, a.cpu_budget)
+
+    import torch
+    import torch.distributed as dist
+    from resource_packing_self_play_amd import _lib
+    from resource_packing_self_play_amd import distributed as rdist
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame
+    from resource_packing_self_play_amd.binpacking.pytorch.NNet import NNetWrapper
+    from resource_packing_self_play_amd.selfplay import BatchedSelfPlay
+
+    rank, world, local = rdist.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    game = BinPackingGame(W, H, N, 1)
+    args = Args(numMCTSSims=sims, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=64)
+    torch.manual_seed(0)
+    nnet = NNetWrapper(game, args)
+    pool = a.pool or 2 * a.games
+    node_cap = sims * (N + 1) + 2
+    sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
+                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph)
+    buf = rank_buffer()
+    ev_every = max(1, a.event_every)
+    phase_ms = np.zeros(4)  # search, planes, evaluator, commit
+    phase_n = 0
+
+    def play_pool(step_idx, timed):
+        nonlocal phase_ms, phase_n
+        wh = make_instances(W, H, N, pool, 100 + (step_idx * world + rank) * pool)
+        sp.start(wh, np.full(pool, W * H, np.int32), buf, first_id=0)
+        waves = 0
+        pending = []
+        while True:
+            for _ in range(32):
+                if timed and waves % ev_every == 0:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                    ev[0].record(); sp.eng.search_step(sync=False)
+                    ev[1].record(); sp.eng.leaf_planes(sp.planes.data_ptr(), sp.G)
+                    ev[2].record(); pi, v = sp._forward_full()
+                    ev[3].record(); sp.eng.commit_eval(pi.data_ptr(), v.data_ptr())
+                    ev[4].record(); sp.steps += 1
+                    pending.append(ev)
+                else:
+                    sp.step()
+                waves += 1
+            if sp.active() == 0:
+                break
+        torch.cuda.synchronize(dev)
+        for ev in pending:
+            phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+            phase_n += 1
+        ids, _, score, moves = sp.eng.pop_finished()
+        assert len(ids) == pool, "pool not finished: %d of %d" % (len(ids), pool)
+        return waves, float(np.mean(score)), float(np.mean(moves))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for w in range(a.warmup):
+        play_pool(w, False)
+    sp.eng.counters(reset=True)
+    barrier()
+    t0 = time.time()
+    waves = 0
+    for k in range(a.steps):
+        wv, mean_score, mean_moves = play_pool(a.warmup + k, True)
+        waves += wv
+    barrier()
+    dt = time.time() - t0
+    c = sp.eng.counters()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(c[k]) for k in _lib.COUNTER_NAMES] + [float(waves)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    tot = dict(zip(list(_lib.COUNTER_NAMES) + ["waves"], tot.tolist()))
+    if rank != 0:
+        return
+    episodes = tot["episodes"]
+    K = 4 * H + (N + 31) // 32 * 4  # key bytes (32-bit rows for W <= 32)
+    if W > 32:
+        K = 8 * H + (N + 31) // 32 * 4
+    A = W * N
+    # algorithmic bytes of the tree walk with THIS layout: per selected node 16 B header + 20 B per
+    # valid edge (P f64, Q f64, N u32) + 6 B (child, action); per path edge backed up 32 B (Q, N, Ns read + write);
+    # per expansion: key write K + one 512 B probe window + key compare K + header 16 + edge init 26 B per valid move +
+    # prior write 8 B per valid move + evaluator output 4A + 4.
+    sel_bytes = 22.0 * tot["path_edges"] + 20.0 * tot["sum_valid_select"]
+    bak_bytes = 32.0 * tot["path_edges"]
+    exp_bytes = tot["expansions"] * (2 * K + 512 + 16 + 4 * A + 4) + 34.0 * tot["sum_valid_leaf"]
+    tree_bytes = sel_bytes + bak_bytes + exp_bytes
+    per_wave = phase_ms / max(phase_n, 1)  # ms per wave: search, planes, evaluator, commit
+    tree_ms = per_wave[0] + per_wave[3]
+    waves_per_rank = tot["waves"] / world
+    tree_bytes_per_wave = tree_bytes / max(tot["waves"], 1)
+    leaves_per_wave = tot["expansions"] / max(tot["waves"], 1)
+    nn_tflops = a.games * flops_leaf / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
+    out = {
+        "metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": episodes / dt, "unit": "episodes/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64 PUCT / f32 Q + CNN, u32 bit-board", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d bin, %d items, %d MCTS sims/move, %d concurrent games per GPU, pool of %d instances per step per GPU"
+                               % (a.config, W, H, N, sims, a.games, pool), "evaluator": "BinPackingNNet FP32 via PyTorch-ROCm, torch.manual_seed(0) init",
+                   "move_rule": "sample ~ visit counts", "parallelism": "dp%d (episodes sharded, no data-path collective)" % world},
+        "expansions_per_s": tot["expansions"] / dt, "simulations_per_s": tot["simulations"] / dt, "episodes": episodes,
+        "waves": tot["waves"], "mean_moves_per_episode": mean_moves, "mean_score": mean_score,
+        "tree_stats": {"path_edges_per_sim": tot["path_edges"] / max(tot["simulations"], 1),
+                       "valid_per_selected_node": tot["sum_valid_select"] / max(tot["path_edges"], 1),
+                       "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
+                       "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
+                       "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
+        "phase_ms_per_wave": {"search": per_wave[0], "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
+        "roofline": {"kernel": "CNN evaluator (all PyTorch-ROCm kernels of one forward over the slot batch)", "bound": "mfma",
+                     "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": None, "flops_per_leaf": flops_leaf, "leaves_per_launch": a.games},
+        "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm",
+                          "achieved": tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": (tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0, "traffic": None,
+                          "bytes_per_wave": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
+                          "leaves_per_wave": leaves_per_wave},
+        "cpu_baseline": cpu_base,
+        "device_bytes": sp.eng.device_bytes,
+    }
+    if cpu_base:
+        out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,9 @@ int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n);
 int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uint64_t *rows /*[count][H]*/,
                  const uint8_t *remaining /*[count][N]*/);
 
+/* Switches the move rule; onehot_examples != 0 records pi as a one-hot on the played action, the greedy branch of
+ * MCTS.getActionProb (greedy_a == 0, MCTS_bpp.py:43-49) that CoachBPP uses after iterStepThreshold (CoachBPP.py:132). */
+int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples);
 /* Changes args.numMCTSSims for the following searches (MCTS_bpp.py:37); rp_search_step stops a slot after this many
  * simulations from its current root. */
 int rp_set_sims(rp_ctx *ctx, int32_t sims);

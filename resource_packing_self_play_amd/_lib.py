@@ -50,6 +50,7 @@ _SIGS = {
     "rp_begin_pool": (C.c_int, [_vp]),
     "rp_set_rank_buffer": (C.c_int, [_vp, _vp, _i32]),
     "rp_set_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "rp_set_move_rule": (C.c_int, [_vp, _i32, _i32]),
     "rp_set_sims": (C.c_int, [_vp, _i32]),
     "rp_last_values": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rp_search_step": (C.c_int, [_vp, _vp]),
@@ -81,7 +82,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build the HIP engine first (python __graft_entry__.py build); "
                               "there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME as /opt/rocm's).  Import torch first so that
+        # librp_engine.so binds to the runtime torch uses: one process must hold exactly one HIP runtime, or device
+        # pointers and streams could not be shared between the engine and the evaluator.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
+        _check_single_hip_runtime()
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
@@ -89,6 +95,17 @@ def load():
             raise ImportError("librp_engine.so ABI %d != %d" % (L.rp_version(), ABI_VERSION))
         _lib = L
     return _lib
+
+
+def _check_single_hip_runtime():
+    try:
+        with open("/proc/self/maps") as f:
+            libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(libs) > 1:
+        raise ImportError("two HIP runtimes are loaded (%s): import torch before anything that loads librp_engine.so"
+                          % ", ".join(sorted(libs)))
 
 
 def _ptr(a):
@@ -183,6 +200,9 @@ class Engine:
         rows = _arr(rows, np.uint64); count = rows.shape[0]
         rows = _arr(rows, np.uint64, (count, self.H)); remaining = _arr(remaining, np.uint8, (count, self.N))
         self._ck(self.L.rp_set_roots(self.h, first, count, _ptr(rows), _ptr(remaining)))
+
+    def set_move_rule(self, move_rule, onehot_examples=False):
+        self._ck(self.L.rp_set_move_rule(self.h, int(move_rule), 1 if onehot_examples else 0))
 
     def set_sims(self, sims):
         self._ck(self.L.rp_set_sims(self.h, int(sims)))

@@ -1,0 +1,101 @@
+"""`NNetWrapper` with the reference's interface (xw_mcts/binpacking/pytorch/NNet.py:17-111): `predict`, `train`,
+`save_checkpoint`, `load_checkpoint`, attribute `.nnet`.  Additions for the batched engine: `predict_batch`
+(device tensors in, device tensors out, feeds rp_commit_eval) and `train_tensors` (replay tensors produced on
+device by rp_examples_tensors).  FP32 throughout: the parity bar against the CPU reference is 1e-5.
+"""
+import os
+
+import numpy as np
+import torch
+from torch import optim
+
+from ...NeuralNet import NeuralNet
+from ...utils import AverageMeter
+from .BinpackingNNet import BinPackingNNet
+
+
+class NNetWrapper(NeuralNet):
+    def __init__(self, game, args):
+        self.args = args
+        self.nnet = BinPackingNNet(game, args)
+        self.board_h, self.board_w = game.getBoardSize()
+        self.action_size = game.getActionSize()
+        self.in_planes = int(args.num_items) + int(args.num_bins)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if getattr(args, "cuda", False) else torch.device("cpu")
+        if self.device.type == "cuda":
+            torch.backends.cudnn.allow_tf32 = False
+            torch.backends.cuda.matmul.allow_tf32 = False
+            self.nnet.to(self.device)
+        self.grad_hook = None  # set by distributed.attach(): all-reduces gradients before optimizer.step()
+        self.log = getattr(args, "verbose", False)
+
+    # ---- inference ---------------------------------------------------------------------------
+    def predict(self, board):
+        """board: numpy state (N+1, H, W) -> (pi, v) numpy float32, shapes (A,) and (1,)  (reference :69-85)"""
+        x = torch.as_tensor(np.asarray(board).astype(np.float64), dtype=torch.float32, device=self.device)
+        x = x.view(-1, self.in_planes, self.board_h, self.board_w)
+        self.nnet.eval()
+        with torch.no_grad():
+            log_pi, v = self.nnet(x)
+        return torch.exp(log_pi).cpu().numpy()[0], v.cpu().numpy()[0]
+
+    def predict_batch(self, planes):
+        """planes: float32 tensor [B, N+1, H, W] on self.device -> (pi [B, A], v [B]) contiguous float32 on device."""
+        self.nnet.eval()
+        with torch.no_grad():
+            log_pi, v = self.nnet(planes)
+            return torch.exp(log_pi).contiguous(), v.reshape(-1).contiguous()
+
+    # ---- training ----------------------------------------------------------------------------
+    def loss_pi(self, targets, outputs):
+        return -torch.sum(targets * outputs) / targets.size()[0]
+
+    def loss_v(self, targets, outputs):
+        return torch.sum((targets - outputs.view(-1)) ** 2) / targets.size()[0]
+
+    def train(self, examples):
+        """examples: list of (state, pi, v) as CoachBPP hands over (reference :27-67)."""
+        boards, pis, vs = zip(*examples)
+        planes = torch.as_tensor(np.array(boards).astype(np.float64), dtype=torch.float32)
+        target_pi = torch.as_tensor(np.array(pis), dtype=torch.float32)
+        target_v = torch.as_tensor(np.array(vs).astype(np.float64), dtype=torch.float32)
+        return self.train_tensors(planes.to(self.device), target_pi.to(self.device), target_v.to(self.device))
+
+    def train_tensors(self, planes, target_pi, target_v):
+        """Same schedule as the reference: a fresh Adam with default hyper-parameters (`args.lr` is never read there,
+        reference :31), `epochs` x floor(len / batch_size) steps, each on `batch_size` examples drawn WITH replacement
+        from NumPy's global stream (:39-43), loss = -sum(pi * log p)/B + sum((v - v_hat)^2)/B (:87-91)."""
+        n = planes.shape[0]
+        optimizer = optim.Adam(self.nnet.parameters())
+        history = []
+        for epoch in range(self.args.epochs):
+            self.nnet.train()
+            pi_losses, v_losses = AverageMeter(), AverageMeter()
+            for _ in range(int(n / self.args.batch_size)):
+                ids = torch.as_tensor(np.random.randint(n, size=self.args.batch_size), device=planes.device)
+                out_pi, out_v = self.nnet(planes.index_select(0, ids))
+                l_pi = self.loss_pi(target_pi.index_select(0, ids), out_pi)
+                l_v = self.loss_v(target_v.index_select(0, ids), out_v)
+                optimizer.zero_grad()
+                (l_pi + l_v).backward()
+                if self.grad_hook is not None:
+                    self.grad_hook(self.nnet)
+                optimizer.step()
+                pi_losses.update(l_pi.item(), self.args.batch_size)
+                v_losses.update(l_v.item(), self.args.batch_size)
+            history.append((pi_losses.avg, v_losses.avg))
+            if self.log:
+                print("EPOCH ::: %d  Loss_pi=%s Loss_v=%s" % (epoch + 1, pi_losses, v_losses))
+        return history
+
+    # ---- checkpoints: {'state_dict': ...} exactly as the reference writes them (reference :93-111) ---------------
+    def save_checkpoint(self, folder="checkpoint", filename="checkpoint.pth.tar"):
+        os.makedirs(folder, exist_ok=True)
+        torch.save({"state_dict": self.nnet.state_dict()}, os.path.join(folder, filename))
+
+    def load_checkpoint(self, folder="checkpoint", filename="checkpoint.pth.tar"):
+        path = os.path.join(folder, filename)
+        if not os.path.exists(path):
+            raise FileNotFoundError("No model in path {}".format(path))
+        checkpoint = torch.load(path, map_location=self.device, weights_only=True)
+        self.nnet.load_state_dict(checkpoint["state_dict"])

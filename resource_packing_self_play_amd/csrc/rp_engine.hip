@@ -97,6 +97,7 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *error;
     // instance pool for auto_restart
     int auto_restart;
+    int onehot_examples;  // greedy self-play records pi as a one-hot on the chosen action (MCTS_bpp.py:43-49)
     long long n_instances;
     u64 first_id;
     const u8 *pool_wh;      // [n_instances][N][2]
@@ -573,7 +574,11 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
             u32 *ec = p.ex_counts + (size_t)idx * p.A;
             for (int a = lane; a < p.A; a += 64) ec[a] = 0u;
             wave_sync();
-            for (u32 q = lane; q < hd.n_valid; q += 64) ec[t.eAct[hd.edge_off + q]] = t.eN[hd.edge_off + q] & NSA_MASK;
+            if (p.onehot_examples) {
+                if (lane == 0) ec[t.eAct[chosen]] = 1u;
+            } else {
+                for (u32 q = lane; q < hd.n_valid; q += 64) ec[t.eAct[hd.edge_off + q]] = t.eN[hd.edge_off + q] & NSA_MASK;
+            }
             if (lane == 0) { p.ex_value[idx] = 0; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
         } else if (lane == 0) {
             set_error(p, ERR_EXAMPLES_CAP);
@@ -1414,6 +1419,14 @@ extern "C" int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uin
     DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)drows, (const u8 *)drem, 0);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_device_error(ctx);
+}
+
+extern "C" int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples) {
+    if (!ctx || move_rule < RP_MOVE_EXTERNAL || move_rule > RP_MOVE_SAMPLE) return fail(ctx, RP_ERR_ARG, "rp_set_move_rule: bad argument");
+    ctx->d.move_rule = move_rule;
+    ctx->d.onehot_examples = onehot_examples ? 1 : 0;
+    ctx->cfg.move_rule = move_rule;
+    return RP_OK;
 }
 
 extern "C" int rp_set_sims(rp_ctx *ctx, int32_t sims) {
