@@ -53,7 +53,11 @@ def rank_buffer():
 
 
 class Args(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
     __setattr__ = dict.__setitem__
 
 

@@ -13,6 +13,7 @@ What it captures:
   q_update.json         the backup expression (N*Q+v)/(N+1) evaluated by NumPy itself for every type mix
   mcts_*.npz            MCTS.getActionProb root counts per move + full tree dumps under table evaluators
   nnet_*.npz            NNetWrapper.predict outputs for seeded weights and for a bundled trained checkpoint
+  train_c2.npz          NNetWrapper.train: weights before / after a few Adam steps, loss_pi / loss_v on a fixed batch
 
 Only stand-ins for absent, unused third-party imports are injected (torchvision, wandb);
 RNG draws inside the reference (np.random.choice in the tie branch) are made deterministic by
@@ -454,11 +455,59 @@ def gen_nnet():
     run("w15_trained", 15, 15, 10, 12, state_dict=sd)
 
 
+def gen_train():
+    """NNetWrapper.train (NNet.py:27-67) for a few steps on CPU from seeded weights and examples: final weights and
+    the loss values of loss_pi / loss_v (NNet.py:87-91) on a fixed batch."""
+    import io
+    import contextlib
+    import torch
+    from binpacking.pytorch.NNet import NNetWrapper
+    META["torch"] = torch.__version__
+    w, h, n = 10, 10, 8
+    g = BinPackingGame(w, h, n, 1)
+    rng = np.random.default_rng(9)
+    examples = []
+    seed = 300
+    while len(examples) < 24:
+        items = items_for(w, h, n, seed); seed += 1
+        state = g.getBinItem(g.getInitBoard(), g.getInitItems(items))
+        while len(examples) < 24:
+            v = valid_mask(g, state)
+            if v.sum() == 0:
+                break
+            counts = rng.integers(0, 30, size=v.shape) * v
+            if counts.sum() == 0:
+                counts = v
+            pi = [float(c) / float(counts.sum()) for c in counts]
+            examples.append((state, pi, int(rng.choice([1, -1]))))
+            b, it = g.getNextState(state[0], int(rng.choice(np.nonzero(v)[0])), state[1:])
+            state = g.getBinItem(b, it)
+    args = Args(cuda=False, num_items=n, num_bins=1, epochs=2, batch_size=8)
+    torch.manual_seed(1)
+    net = NNetWrapper(g, args)
+    init = {"i__" + k: t.detach().numpy().copy() for k, t in net.nnet.state_dict().items()}
+    boards = torch.FloatTensor(np.array([e[0] for e in examples[:8]]).astype(np.float64))
+    tp = torch.FloatTensor(np.array([e[1] for e in examples[:8]])); tv = torch.FloatTensor(np.array([e[2] for e in examples[:8]]).astype(np.float64))
+    net.nnet.eval()
+    with torch.no_grad():
+        op, ov = net.nnet(boards)
+    l_pi, l_v = float(net.loss_pi(tp, op)), float(net.loss_v(tv, ov))
+    np.random.seed(77)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        net.train(examples)
+    final = {"f__" + k: t.detach().numpy().copy() for k, t in net.nnet.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "train_c2.npz"), meta=json.dumps(META), W=w, H=h, N=n, epochs=2, batch_size=8, np_seed=77,
+                        planes=np.stack([e[0] for e in examples]).astype(np.uint8), pi=np.array([e[1] for e in examples], np.float64),
+                        v=np.array([e[2] for e in examples], np.int8), loss_pi=l_pi, loss_v=l_v, **init, **final)
+    print("wrote train_c2.npz", l_pi, l_v)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet"]
+    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet", "train"]
     if "items" in which: gen_items()
     if "rules" in which: gen_game_rules()
     if "reward" in which: gen_ranked_reward()
     if "q" in which: gen_q_update()
     if "mcts" in which: gen_mcts()
     if "nnet" in which: gen_nnet()
+    if "train" in which: gen_train()
