@@ -24,6 +24,7 @@ class NNetWrapper(NeuralNet):
         self.device = torch.device("cuda", torch.cuda.current_device()) if getattr(args, "cuda", False) else torch.device("cpu")
         if self.device.type == "cuda":
             torch.backends.cudnn.allow_tf32 = False
+            torch.backends.cudnn.benchmark = True  # let MIOpen pick its fastest FP32 convolution per shape
             torch.backends.cuda.matmul.allow_tf32 = False
             self.nnet.to(self.device)
         self.grad_hook = None  # set by distributed.attach(): all-reduces gradients before optimizer.step()

