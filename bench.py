@@ -185,6 +185,7 @@ def main():
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph)
+    sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)
     phase_ms = np.zeros(4)  # search, planes, evaluator, commit
@@ -202,7 +203,7 @@ def main():
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                     ev[0].record(); sp.eng.search_step(sync=False)
                     ev[1].record(); sp.eng.leaf_planes(sp.planes.data_ptr(), sp.G)
-                    ev[2].record(); pi, v = sp._forward_full()
+                    ev[2].record(); pi, v = sp.nnet.predict_batch(sp.planes)
                     ev[3].record(); sp.eng.commit_eval(pi.data_ptr(), v.data_ptr())
                     ev[4].record(); sp.steps += 1
                     pending.append(ev)

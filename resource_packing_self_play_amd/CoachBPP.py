@@ -17,7 +17,6 @@ entropy:
 import logging
 import os
 import pickle
-from collections import deque
 
 import numpy as np
 
@@ -96,7 +95,10 @@ class CoachBPP:
         mine = rdist.shard(args.numEps)
         sp = self._driver()
         greedy = i > args.iterStepThreshold  # :132
-        sp.eng.set_move_rule(_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, onehot_examples=greedy)
+        if getattr(self, "_greedy_mode", None) != greedy:
+            sp.eng.set_move_rule(_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, onehot_examples=greedy)
+            sp.invalidate_graph()  # kernel arguments are baked into the captured wave
+            self._greedy_mode = greedy
         sp.clear_examples()
         ids, outcome, score, moves, stats = sp.run(wh[mine], np.full(len(mine), self.items_total_area, np.int32), self.rewards_list,
                                                    first_id=0)

@@ -1421,6 +1421,13 @@ extern "C" int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uin
     return check_device_error(ctx);
 }
 
+extern "C" int rp_set_stream(rp_ctx *ctx, void *stream) {
+    if (!ctx) return RP_ERR_ARG;
+    ctx->stream = (hipStream_t)stream;
+    ctx->cfg.stream = stream;
+    return RP_OK;
+}
+
 extern "C" int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples) {
     if (!ctx || move_rule < RP_MOVE_EXTERNAL || move_rule > RP_MOVE_SAMPLE) return fail(ctx, RP_ERR_ARG, "rp_set_move_rule: bad argument");
     ctx->d.move_rule = move_rule;

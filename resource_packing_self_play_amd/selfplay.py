@@ -42,37 +42,49 @@ class BatchedSelfPlay:
     def close(self):
         self.eng.close()
 
-    # ---- evaluator over the full slot batch (static shapes, graph friendly) ------------------------------------------
-    def _forward_full(self):
-        if not self.use_graph:
-            return self.nnet.predict_batch(self.planes)
-        if self._graph is None:
-            side = torch.cuda.Stream(self.device)
-            side.wait_stream(self.stream)
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    self.nnet.predict_batch(self.planes)
-            self.stream.wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, stream=side):
-                self._pi, self._v = self.nnet.predict_batch(self.planes)
-            torch.cuda.synchronize(self.device)
-        self._graph.replay()
-        return self._pi, self._v
+    # ---- one simulation wave: search -> planes -> CNN -> commit, static shapes, replayed from one HIP graph -----------
+    def _wave_eager(self):
+        self.eng.search_step(sync=False)
+        self.eng.leaf_planes(self.planes.data_ptr(), self.G)
+        self._pi, self._v = self.nnet.predict_batch(self.planes)
+        self.eng.commit_eval(self._pi.data_ptr(), self._v.data_ptr())
+
+    def prepare(self):
+        """Warms the evaluator up (MIOpen picks its kernels on the first calls) and captures the whole wave -- the engine's
+        kernels and the CNN's -- into one HIP graph, so a wave costs one graph launch instead of ~40 kernel launches."""
+        if self._graph is not None or not self.use_graph:
+            return
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(self.stream)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self.nnet.predict_batch(self.planes)
+        self.stream.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        self.eng.set_stream(side.cuda_stream)
+        try:
+            with torch.cuda.graph(graph, stream=side):
+                self._wave_eager()
+        finally:
+            self.eng.set_stream(self.stream.cuda_stream)
+        torch.cuda.synchronize(self.device)
+        self._graph = graph
 
     def invalidate_graph(self):
-        """Call after the evaluator's weights were REPLACED (not updated in place); in-place optimizer steps are fine."""
+        """Call after the evaluator's weights were REPLACED (not updated in place), or after set_move_rule / set_sims:
+        kernel arguments are baked into the captured graph."""
         self._graph = None
 
-    def step(self, sync=False):
-        """One lock-step simulation wave.  Returns the number of evaluated leaves when sync=True."""
-        n = self.eng.search_step(sync=sync)
-        self.eng.leaf_planes(self.planes.data_ptr(), self.G)
-        pi, v = self._forward_full()
-        self.eng.commit_eval(pi.data_ptr(), v.data_ptr())
+    def step(self):
+        """One lock-step simulation wave for every slot."""
+        if self.use_graph:
+            if self._graph is None:
+                self.prepare()
+            self._graph.replay()
+        else:
+            self._wave_eager()
         self.steps += 1
-        return n
 
     # ---- whole pools ---------------------------------------------------------------------------
     def start(self, item_wh, total_area, rewards_list=(), first_id=0):
