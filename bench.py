@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default 2 x games)")
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--edge-factor", type=int, default=72, help="edge arena = node arena x this")
+    ap.add_argument("--groups", type=int, default=2, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
+    ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -184,7 +186,7 @@ def main():
     pool = a.pool or 2 * a.games
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
-                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph)
+                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)
@@ -197,26 +199,31 @@ def main():
         sp.start(wh, np.full(pool, W * H, np.int32), buf, first_id=0)
         waves = 0
         pending = []
+        g0 = sp.groups[0]
         while True:
             for _ in range(32):
-                if timed and waves % ev_every == 0:
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-                    ev[0].record(); sp.eng.search_step(sync=False)
-                    ev[1].record(); sp.eng.leaf_planes(sp.planes.data_ptr(), sp.G)
-                    ev[2].record(); pi, v = sp.nnet.predict_batch(sp.planes)
-                    ev[3].record(); sp.eng.commit_eval(pi.data_ptr(), v.data_ptr())
-                    ev[4].record(); sp.steps += 1
-                    pending.append(ev)
+                if timed and waves % ev_every == 0:  # this wave of group 0 runs eagerly between HIP events on its stream
+                    with torch.cuda.stream(g0.stream):
+                        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                        ev[0].record(); g0.eng.search_step(sync=False)
+                        ev[1].record(); g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
+                        ev[2].record(); pi, v = sp.nnet.predict_batch(g0.planes)
+                        ev[3].record(); g0.eng.commit_eval(pi.data_ptr(), v.data_ptr())
+                        ev[4].record()
+                    for g in sp.groups[1:]:
+                        sp.step_group(g)
+                    sp.steps += 1
+                    pending.append((ev, pi, v))
                 else:
                     sp.step()
                 waves += 1
             if sp.active() == 0:
                 break
         torch.cuda.synchronize(dev)
-        for ev in pending:
+        for ev, _, _ in pending:
             phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
             phase_n += 1
-        ids, _, score, moves = sp.eng.pop_finished()
+        ids, _, score, moves = sp.pop_finished()
         assert len(ids) == pool, "pool not finished: %d of %d" % (len(ids), pool)
         return waves, float(np.mean(score)), float(np.mean(moves))
 
@@ -227,7 +234,7 @@ def main():
 
     for w in range(a.warmup):
         play_pool(w, False)
-    sp.eng.counters(reset=True)
+    sp.counters(reset=True)
     barrier()
     t0 = time.time()
     waves = 0
@@ -236,7 +243,7 @@ def main():
         waves += wv
     barrier()
     dt = time.time() - t0
-    c = sp.eng.counters()
+    c = sp.counters()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(c[k]) for k in _lib.COUNTER_NAMES] + [float(waves)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -261,10 +268,10 @@ def main():
     tree_bytes = sel_bytes + bak_bytes + exp_bytes
     per_wave = phase_ms / max(phase_n, 1)  # ms per wave: search, planes, evaluator, commit
     tree_ms = per_wave[0] + per_wave[3]
-    waves_per_rank = tot["waves"] / world
-    tree_bytes_per_wave = tree_bytes / max(tot["waves"], 1)
-    leaves_per_wave = tot["expansions"] / max(tot["waves"], 1)
-    nn_tflops = a.games * flops_leaf / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
+    launches = max(tot["waves"], 1) * len(sp.groups)  # one k_search / evaluator / k_commit launch per group and wave
+    tree_bytes_per_wave = tree_bytes / launches
+    leaves_per_wave = tot["expansions"] / launches
+    nn_tflops = sp.groups[0].G * flops_leaf / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
     out = {
         "metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": episodes / dt, "unit": "episodes/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -279,17 +286,17 @@ def main():
                        "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
                        "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
                        "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
-        "phase_ms_per_wave": {"search": per_wave[0], "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
+        "phase_ms_per_launch": {"search": per_wave[0], "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
         "roofline": {"kernel": "CNN evaluator (all PyTorch-ROCm kernels of one forward over the slot batch)", "bound": "mfma",
                      "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
-                     "traffic": None, "flops_per_leaf": flops_leaf, "leaves_per_launch": a.games},
+                     "traffic": None, "flops_per_leaf": flops_leaf, "leaves_per_launch": sp.groups[0].G},
         "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm",
                           "achieved": tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": (tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0, "traffic": None,
-                          "bytes_per_wave": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
-                          "leaves_per_wave": leaves_per_wave},
+                          "bytes_per_launch": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
+                          "leaves_per_launch": leaves_per_wave, "slots_per_launch": sp.groups[0].G},
         "cpu_baseline": cpu_base,
-        "device_bytes": sp.eng.device_bytes,
+        "device_bytes": sp.device_bytes,
     }
     if cpu_base:
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]

@@ -132,6 +132,10 @@ int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uint64_t *rows
 /* Moves the context to another HIP stream (e.g. the side stream of a hipGraph capture: rp_search_step(ctx, NULL),
  * rp_leaf_planes and rp_commit_eval only enqueue work, so a whole simulation wave can be captured and replayed). */
 int rp_set_stream(rp_ctx *ctx, void *stream);
+/* Bounds the simulations one slot runs inside one rp_search_step (0 = unbounded, the default).  Slots near the end of a
+ * game hit cached terminal states (Es, MCTS_bpp.py:81-83) and need no evaluator; the cap keeps such a slot from stretching
+ * the launch for everyone.  Scheduling only -- results are identical for any value. */
+int rp_set_step_cap(rp_ctx *ctx, int32_t max_sims_per_step);
 /* Switches the move rule; onehot_examples != 0 records pi as a one-hot on the played action, the greedy branch of
  * MCTS.getActionProb (greedy_a == 0, MCTS_bpp.py:43-49) that CoachBPP uses after iterStepThreshold (CoachBPP.py:132). */
 int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples);

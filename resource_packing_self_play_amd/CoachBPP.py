@@ -73,7 +73,8 @@ class CoachBPP:
                                              seed=int(getattr(self.args, "seed", 0) or 0) * 1000003 + rdist.rank(),
                                              node_cap=int(getattr(self.args, "node_cap", 0) or 0),
                                              edge_cap=int(getattr(self.args, "edge_cap", 0) or 0),
-                                             max_examples=per_rank * moves_cap, use_graph=bool(getattr(self.args, "use_graph", True)))
+                                             max_examples=2 * per_rank * moves_cap, use_graph=bool(getattr(self.args, "use_graph", True)),
+                                             groups=int(getattr(self.args, "groups", 2) or 2))
         return self._selfplay
 
     def selfPlayIteration(self, i):
@@ -96,8 +97,7 @@ class CoachBPP:
         sp = self._driver()
         greedy = i > args.iterStepThreshold  # :132
         if getattr(self, "_greedy_mode", None) != greedy:
-            sp.eng.set_move_rule(_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, onehot_examples=greedy)
-            sp.invalidate_graph()  # kernel arguments are baked into the captured wave
+            sp.set_move_rule(_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, onehot_examples=greedy)  # re-captures the waves
             self._greedy_mode = greedy
         sp.clear_examples()
         ids, outcome, score, moves, stats = sp.run(wh[mine], np.full(len(mine), self.items_total_area, np.int32), self.rewards_list,

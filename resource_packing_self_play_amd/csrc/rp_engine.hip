@@ -59,6 +59,7 @@ struct NodeHdr {   // 16 bytes, one dwordx4 load per visited node
 
 struct DP {  // device view of a context, passed by value to every kernel
     int W, H, N, A, G, sims, node_cap, edge_cap, table_cap, KW, RW, RMW, move_rule;
+    int step_cap;  // max simulations a slot runs in one k_search launch (0 = until it needs the evaluator)
     u32 magicW;  // a / W == (a * magicW) >> 20 for a < 8192
     double cpuct;
     u64 seed, tie_salt;
@@ -667,7 +668,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
+    int launched = 0;
     for (;;) {
+        // A slot near the end of its game runs many evaluator-free simulations (terminal hits); the cap bounds the
+        // launch's tail so one such slot cannot stall the whole wave.  Pure scheduling: results do not depend on it.
+        if (p.step_cap > 0 && launched >= p.step_cap) break;
         if (phase == RP_PHASE_MOVE_READY) {
             if (p.move_rule == RP_MOVE_EXTERNAL) break;
             play_move<row_t>(p, t, g, root, -1, c);
@@ -739,6 +744,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
         if (lane + 64 < depth) t.backup_entry(pn1, pe1, v, vkind);
         if (lane == 0) { p.last_v[g] = v; p.last_vkind[g] = (int)vkind; }
         sims_done++;
+        launched++;
         c[CNT_SIMS]++;
         wave_sync();
     }
@@ -746,7 +752,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
     c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
     if (lane == 0) {
         if (phase != RP_PHASE_EPISODE_DONE && phase != RP_PHASE_IDLE) p.phase[g] = phase;
-        if (phase == RP_PHASE_WAIT_EVAL || phase == RP_PHASE_FAILED) p.sims_done[g] = sims_done;
+        if (phase == RP_PHASE_WAIT_EVAL || phase == RP_PHASE_FAILED || phase == RP_PHASE_RUNNING) p.sims_done[g] = sims_done;
     }
     add_counters(p, c);
 }
@@ -1425,6 +1431,12 @@ extern "C" int rp_set_stream(rp_ctx *ctx, void *stream) {
     if (!ctx) return RP_ERR_ARG;
     ctx->stream = (hipStream_t)stream;
     ctx->cfg.stream = stream;
+    return RP_OK;
+}
+
+extern "C" int rp_set_step_cap(rp_ctx *ctx, int32_t max_sims_per_step) {
+    if (!ctx || max_sims_per_step < 0) return fail(ctx, RP_ERR_ARG, "rp_set_step_cap: bad argument");
+    ctx->d.step_cap = max_sims_per_step;
     return RP_OK;
 }
 

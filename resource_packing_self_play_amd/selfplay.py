@@ -1,15 +1,18 @@
 """Batched self-play driver: the many-games-at-once counterpart of `CoachBPP.executeEpisode`
 (xw_mcts/CoachBPP.py:50-99) that `CoachBPP.learn` and `bench.py` run.
 
-Every engine slot plays one episode at a time; all slots advance in lock step, one evaluator call per step:
+Every engine slot plays one episode at a time.  The slots of a GPU are split into `groups` (default 2), each with its
+own engine context, HIP stream and captured HIP graph of one simulation WAVE:
 
     rp_search_step      select / descend / terminal backups on device until each slot needs a leaf evaluated
     rp_leaf_planes      leaf states -> FP32 NCHW planes written straight into the evaluator's input tensor
-    NNetWrapper.predict_batch   the CNN through PyTorch-ROCm (FP32, optionally replayed from a captured HIP graph)
+    NNetWrapper.predict_batch   the CNN through PyTorch-ROCm (FP32)
     rp_commit_eval      mask / renormalise / expand / backup on device
 
-Moves are played on device (`RP_MOVE_SAMPLE` or `RP_MOVE_ARGMAX_FIRST`) and a finished slot immediately pulls the
-next instance of the pool, so the evaluator batch stays full until the pool runs dry.
+The groups' waves are launched alternately on their streams, so the latency-bound tree walk of one group runs while the
+CNN of the other occupies the matrix cores.  Moves are played on device (`RP_MOVE_SAMPLE` / `RP_MOVE_ARGMAX_FIRST`) and a
+finished slot immediately pulls the next instance of its group's pool, so the evaluator batch stays full until the pool
+runs dry.
 """
 import time
 
@@ -19,85 +22,145 @@ import torch
 from . import _lib
 
 
+class _Group:
+    def __init__(self, owner, index, games, seed):
+        self.index = index
+        self.G = games
+        self.stream = torch.cuda.Stream(owner.device)
+        self.eng = _lib.Engine(owner.W, owner.H, owner.N, games, int(owner.args.numMCTSSims), cpuct=float(owner.args.cpuct),
+                               alpha=float(owner.args.alpha), move_rule=owner.move_rule, seed=seed, tie_salt=seed ^ 0x5DEECE66D,
+                               node_cap=owner.node_cap, edge_cap=owner.edge_cap, device=owner.device.index or 0,
+                               stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group)
+        self.eng.set_step_cap(owner.step_cap)
+        self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
+        self.graph = None
+        self.pi = self.v = None
+
+    def wave_eager(self, nnet):
+        self.eng.search_step(sync=False)
+        self.eng.leaf_planes(self.planes.data_ptr(), self.G)
+        self.pi, self.v = nnet.predict_batch(self.planes)
+        self.eng.commit_eval(self.pi.data_ptr(), self.v.data_ptr())
+
+
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
-        self.G = int(games)
         if nnet.device.type != "cuda":
             raise RuntimeError("BatchedSelfPlay needs the evaluator on the GPU (args.cuda = True); there is no CPU path")
         self.device = nnet.device if device is None else device
-        self.stream = torch.cuda.current_stream(self.device)
-        self.eng = _lib.Engine(self.W, self.H, self.N, self.G, int(args.numMCTSSims), cpuct=float(args.cpuct), alpha=float(args.alpha),
-                               move_rule=move_rule, seed=seed, tie_salt=seed ^ 0x5DEECE66D, node_cap=node_cap, edge_cap=edge_cap,
-                               device=self.device.index or 0, stream=self.stream.cuda_stream, auto_restart=1, max_examples=max_examples)
-        self.planes = torch.zeros((self.G, self.N + 1, self.H, self.W), dtype=torch.float32, device=self.device)
+        groups = max(1, min(int(groups), int(games)))
+        self.G = int(games)
+        self.move_rule, self.node_cap, self.edge_cap, self.step_cap = move_rule, node_cap, edge_cap, int(step_cap)
+        self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
         self.use_graph = use_graph
-        self._graph = None
-        self._pi = self._v = None
+        sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
+        self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0
+        self.first_id = 0
+
+    @property
+    def eng(self):
+        """First group's engine (single-group callers, tests)."""
+        return self.groups[0].eng
 
     def close(self):
-        self.eng.close()
+        for g in self.groups:
+            g.eng.close()
 
-    # ---- one simulation wave: search -> planes -> CNN -> commit, static shapes, replayed from one HIP graph -----------
-    def _wave_eager(self):
-        self.eng.search_step(sync=False)
-        self.eng.leaf_planes(self.planes.data_ptr(), self.G)
-        self._pi, self._v = self.nnet.predict_batch(self.planes)
-        self.eng.commit_eval(self._pi.data_ptr(), self._v.data_ptr())
+    @property
+    def device_bytes(self):
+        return sum(g.eng.device_bytes for g in self.groups)
 
+    # ---- waves -----------------------------------------------------------------------------------
     def prepare(self):
-        """Warms the evaluator up (MIOpen picks its kernels on the first calls) and captures the whole wave -- the engine's
-        kernels and the CNN's -- into one HIP graph, so a wave costs one graph launch instead of ~40 kernel launches."""
-        if self._graph is not None or not self.use_graph:
+        """Warms the evaluator up (MIOpen picks its kernels on the first calls) and captures every group's wave -- the
+        engine's kernels and the CNN's -- into one HIP graph each, so a wave costs one graph launch instead of ~40 kernel
+        launches."""
+        if not self.use_graph:
             return
-        side = torch.cuda.Stream(self.device)
-        side.wait_stream(self.stream)
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                self.nnet.predict_batch(self.planes)
-        self.stream.wait_stream(side)
-        torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
-        self.eng.set_stream(side.cuda_stream)
-        try:
-            with torch.cuda.graph(graph, stream=side):
-                self._wave_eager()
-        finally:
-            self.eng.set_stream(self.stream.cuda_stream)
-        torch.cuda.synchronize(self.device)
-        self._graph = graph
+        for g in self.groups:
+            if g.graph is not None:
+                continue
+            torch.cuda.synchronize(self.device)
+            with torch.cuda.stream(g.stream):
+                for _ in range(3):
+                    self.nnet.predict_batch(g.planes)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=g.stream):
+                g.wave_eager(self.nnet)
+            torch.cuda.synchronize(self.device)
+            g.graph = graph
 
     def invalidate_graph(self):
         """Call after the evaluator's weights were REPLACED (not updated in place), or after set_move_rule / set_sims:
-        kernel arguments are baked into the captured graph."""
-        self._graph = None
+        kernel arguments are baked into the captured graphs."""
+        for g in self.groups:
+            g.graph = None
+
+    def step_group(self, g):
+        with torch.cuda.stream(g.stream):
+            if self.use_graph:
+                if g.graph is None:
+                    self.prepare()
+                g.graph.replay()
+            else:
+                g.wave_eager(self.nnet)
 
     def step(self):
-        """One lock-step simulation wave for every slot."""
-        if self.use_graph:
-            if self._graph is None:
-                self.prepare()
-            self._graph.replay()
-        else:
-            self._wave_eager()
+        """One simulation wave for every group (each on its own stream)."""
+        for g in self.groups:
+            self.step_group(g)
         self.steps += 1
 
-    # ---- whole pools ---------------------------------------------------------------------------
+    def set_move_rule(self, move_rule, onehot_examples=False):
+        for g in self.groups:
+            g.eng.set_move_rule(move_rule, onehot_examples)
+        self.move_rule = move_rule
+        self.invalidate_graph()
+
+    # ---- whole pools -------------------------------------------------------------------------------
     def start(self, item_wh, total_area, rewards_list=(), first_id=0):
-        self.eng.set_rank_buffer(np.asarray(list(rewards_list), dtype=np.float64))
+        """Instance i of the pool goes to group i % groups; its episode id is first_id + i."""
         item_wh = np.ascontiguousarray(item_wh, dtype=np.uint8)
         total_area = np.ascontiguousarray(total_area, dtype=np.int32)
-        self.eng._ck(self.eng.L.rp_set_instance_pool(self.eng.h, item_wh.shape[0], _lib._ptr(item_wh), _lib._ptr(total_area), int(first_id)))
-        self.eng._ck(self.eng.L.rp_begin_pool(self.eng.h))
+        buf = np.asarray(list(rewards_list), dtype=np.float64)
+        self.first_id = int(first_id)
         self.n_instances = item_wh.shape[0]
+        k = len(self.groups)
+        for g in self.groups:
+            wh_g = np.ascontiguousarray(item_wh[g.index::k]); area_g = np.ascontiguousarray(total_area[g.index::k])
+            g.eng.set_rank_buffer(buf)
+            g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), 0))
+            g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
     def active(self):
-        ph, _, _, _ = self.eng.status()
-        return int(np.isin(ph, (_lib.PHASE_RUNNING, _lib.PHASE_WAIT_EVAL, _lib.PHASE_MOVE_READY)).sum())
+        n = 0
+        for g in self.groups:
+            ph, _, _, _ = g.eng.status()
+            n += int(np.isin(ph, (_lib.PHASE_RUNNING, _lib.PHASE_WAIT_EVAL, _lib.PHASE_MOVE_READY)).sum())
+        return n
+
+    def pop_finished(self):
+        """(episode ids, outcomes, scores, moves) of the episodes finished since the last call, sorted by id."""
+        k = len(self.groups)
+        parts = []
+        for g in self.groups:
+            ids, oc, sc, mv = g.eng.pop_finished()
+            parts.append((ids.astype(np.int64) * k + g.index + self.first_id, oc, sc, mv))
+        ids = np.concatenate([p[0] for p in parts]); order = np.argsort(ids, kind="stable")
+        return tuple(np.concatenate([p[j] for p in parts])[order] for j in range(4))
+
+    def counters(self, reset=False):
+        tot = dict.fromkeys(_lib.COUNTER_NAMES, 0)
+        for g in self.groups:
+            for name, val in g.eng.counters(reset=reset).items():
+                tot[name] += val
+        return tot
 
     def run(self, item_wh, total_area, rewards_list=(), first_id=0, poll=16, max_steps=None):
         """Plays every instance of the pool to the end.  Returns (episode ids, outcomes, scores, moves) sorted by id,
@@ -112,25 +175,31 @@ class BatchedSelfPlay:
                 break
         torch.cuda.synchronize(self.device)
         dt = time.time() - t0
-        ids, outcome, score, moves = self.eng.pop_finished()
-        order = np.argsort(ids, kind="stable")
-        stats = self.eng.counters()
+        ids, outcome, score, moves = self.pop_finished()
+        stats = self.counters()
         stats.update(seconds=dt, steps=self.steps - steps0, episodes_finished=len(ids))
-        return ids[order], outcome[order], score[order], moves[order], stats
+        return ids, outcome, score, moves, stats
 
     # ---- replay ---------------------------------------------------------------------------------
     def examples(self):
         """(planes [E, N+1, H, W], pi [E, A], value [E]) float32 device tensors of everything recorded so far."""
-        n = _lib._i64(0)
-        self.eng._ck(self.eng.L.rp_examples_count(self.eng.h, _lib.C.byref(n)))
-        e = n.value
-        planes = torch.empty((e, self.N + 1, self.H, self.W), dtype=torch.float32, device=self.device)
-        pi = torch.empty((e, self.A), dtype=torch.float32, device=self.device)
-        value = torch.empty((e,), dtype=torch.float32, device=self.device)
-        if e:
-            self.eng._ck(self.eng.L.rp_examples_tensors(self.eng.h, 0, e, _lib.C.c_void_p(planes.data_ptr()), _lib.C.c_void_p(pi.data_ptr()),
-                                                        _lib.C.c_void_p(value.data_ptr())))
-        return planes, pi, value
+        out = []
+        for g in self.groups:
+            n = _lib._i64(0)
+            g.eng._ck(g.eng.L.rp_examples_count(g.eng.h, _lib.C.byref(n)))
+            e = n.value
+            # allocated on the caller's stream; the engine fills them on the group's stream between two device syncs
+            planes = torch.empty((e, self.N + 1, self.H, self.W), dtype=torch.float32, device=self.device)
+            pi = torch.empty((e, self.A), dtype=torch.float32, device=self.device)
+            value = torch.empty((e,), dtype=torch.float32, device=self.device)
+            torch.cuda.synchronize(self.device)
+            if e:
+                g.eng._ck(g.eng.L.rp_examples_tensors(g.eng.h, 0, e, _lib.C.c_void_p(planes.data_ptr()), _lib.C.c_void_p(pi.data_ptr()),
+                                                      _lib.C.c_void_p(value.data_ptr())))
+            out.append((planes, pi, value))
+        torch.cuda.synchronize(self.device)
+        return tuple(torch.cat([o[j] for o in out]) for j in range(3))
 
     def clear_examples(self):
-        self.eng._ck(self.eng.L.rp_examples_clear(self.eng.h))
+        for g in self.groups:
+            g.eng._ck(g.eng.L.rp_examples_clear(g.eng.h))
