@@ -69,13 +69,13 @@ typedef struct rp_config {
     double cpuct;          /* args.cpuct (MCTS_bpp.py:114,117) */
     double alpha;          /* args.alpha (MCTS_bpp.py:79) */
     int32_t node_cap;      /* per-game node arena; 0 = sims * (N + 1) + 2 */
-    int32_t edge_cap;      /* per-game edge arena; 0 = automatic */
+    int32_t edge_cap;      /* per-game legal-move arena (one 6-byte entry per legal move of every node); 0 = automatic */
     int32_t move_rule;     /* rp_move_rule */
     int32_t auto_restart;  /* 1: a finished slot pulls the next instance from the pool set by rp_set_instance_pool */
     uint64_t seed;         /* RNG seed for RP_MOVE_SAMPLE and the tie rule */
     uint64_t tie_salt;     /* salt of the deterministic stand-in for np.random.choice([1,-1]) (BinPackingGame.py:212) */
     int32_t device;        /* HIP device ordinal */
-    int32_t reserved0;
+    int32_t vis_cap;       /* per-game visited-edge arena (26-byte entries); 0 = automatic */
     void *stream;          /* hipStream_t; NULL = the default stream */
     int64_t max_examples;  /* capacity of the replay buffer in examples; 0 = none recorded */
 } rp_config;
@@ -199,8 +199,8 @@ int rp_examples_clear(rp_ctx *ctx);
 /* Sizes of slot g's tree: nodes and edges in use. */
 int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out);
 /* Host copy of slot g's tree.  Node i: rows u64[H], remaining u8[N], term i8 (0 / +-1 = Es),
- * term_kind u8, expanded u8, ns u32, edge_off u32, n_valid u32.  Edge e: action u16, P f64, Q f64,
- * nsa u32, q_kind u8, child u32 (0xFFFFFFFF = not linked yet). */
+ * term_kind u8, expanded u8, ns u32, edge_off u32, n_valid u32.  Edge e (one per legal move, dense view of the sparse
+ * device layout): action u16, P f64, Q f64, nsa u32, q_kind u8, child u32 (0xFFFFFFFF = not linked yet). */
 int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint8_t *node_remaining, int8_t *node_term,
                  uint8_t *node_term_kind, uint8_t *node_expanded, uint32_t *node_ns, uint32_t *node_edge_off,
                  uint32_t *node_n_valid, uint16_t *edge_action, double *edge_p, double *edge_q, uint32_t *edge_nsa,

@@ -25,7 +25,7 @@ class RpConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("games", C.c_int32),
                 ("sims", C.c_int32), ("cpuct", C.c_double), ("alpha", C.c_double), ("node_cap", C.c_int32),
                 ("edge_cap", C.c_int32), ("move_rule", C.c_int32), ("auto_restart", C.c_int32), ("seed", C.c_uint64),
-                ("tie_salt", C.c_uint64), ("device", C.c_int32), ("reserved0", C.c_int32), ("stream", C.c_void_p),
+                ("tie_salt", C.c_uint64), ("device", C.c_int32), ("vis_cap", C.c_int32), ("stream", C.c_void_p),
                 ("max_examples", C.c_int64)]
 
 
@@ -129,11 +129,11 @@ class Engine:
     """Thin object wrapper of one rp_ctx (one per process and GPU)."""
 
     def __init__(self, W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=MOVE_EXTERNAL, seed=0, tie_salt=0,
-                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0):
+                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0):
         self.L = load()
         self.W, self.H, self.N, self.A, self.G, self.sims = int(W), int(H), int(N), int(W) * int(N), int(games), int(sims)
         cfg = RpConfig(ABI_VERSION, W, H, N, games, sims, float(cpuct), float(alpha), node_cap, edge_cap, move_rule,
-                       auto_restart, seed, tie_salt, device, 0, stream or None, max_examples)
+                       auto_restart, seed, tie_salt, device, vis_cap, stream or None, max_examples)
         h = _vp()
         rc = self.L.rp_create(C.byref(cfg), C.byref(h))
         if rc != 0:

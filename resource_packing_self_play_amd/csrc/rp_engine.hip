@@ -5,10 +5,11 @@
 // Execution model: one 64-lane wavefront owns one game slot.  A grid row lives in the lane with the
 // same index (rows are W-bit masks, W <= 64, H <= 64), so the reference's per-cell Python loops
 // (BinPackingLogic.py:47-109) become popcounts, ballots and readlanes over a register-resident
-// board.  Every tree of a slot is a structure of arrays in HBM: 16-byte node headers, bit-packed
-// node keys (the state), and per-node CONTIGUOUS edge runs (valid moves only) in separate
-// P / Q / N / child / action arrays so a wave reads a node's edges as coalesced 64-lane loads.
-// Transpositions (the reference keys its dicts by the full state, MCTS_bpp.py:20-26,76) go through a
+// board.  Every tree of a slot is a structure of arrays in HBM: 32-byte node headers, bit-packed
+// node keys (the state), per-node CONTIGUOUS runs of the legal moves' (action u16, prior f32) -- 6 bytes
+// per legal move, written once at expansion -- and per-node blocks of VISITED edges only
+// (index, P, Q, N, child; grown by doubling), because a search visits ~2 % of the edges it creates.
+// A wave reads a node's priors and visited block as coalesced 64-lane loads.  Transpositions (the reference keys its dicts by the full state, MCTS_bpp.py:20-26,76) go through a
 // per-slot open-addressing table probed 64 slots per wave instruction.
 //
 // Numerics: compiled with -ffp-contract=off; the PUCT score is float64, Q follows the NumPy promotion
@@ -45,20 +46,26 @@ typedef unsigned char u8;
 
 enum { CNT_SIMS = 0, CNT_EXPAND, CNT_TERMINAL, CNT_PATH, CNT_NVALID_SEL, CNT_NVALID_LEAF, CNT_TRANSPOSE, CNT_NODES,
        CNT_MOVES, CNT_EPISODES, CNT_PROBES, CNT_KEYBYTES, CNT_N };
-enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7 };
+enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7, ERR_VIS_CAP = 8 };
 
-struct NodeHdr {   // 16 bytes, one dwordx4 load per visited node
-    u32 ns;        // Ns[s]          (MCTS_bpp.py:103,138)
-    u32 edge_off;  // first edge of this node in the slot's edge arrays
-    u32 n_valid;   // number of valid moves = edges (Vs[s], :102)
-    int8_t term;   // Es[s]: 0 not ended, +1 / -1 ranked outcome (:78-83)
-    u8 term_kind;  // RP_KIND_WEAK (Python int) or RP_KIND_F64 (np.int64 from the tie branch)
-    u8 expanded;   // s in Ps
-    u8 pad;
+struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
+    u32 ns;         // Ns[s]          (MCTS_bpp.py:103,138)
+    u32 prior_off;  // first entry of this node's legal-move run in pAct / pPi
+    u32 vis_off;    // first entry of its visited-edge block
+    u16 n_valid;    // number of legal moves (Vs[s], :102)
+    u16 vis_n;      // visited edges = entries in use
+    u16 vis_cap;    // entries allocated (0 until the node is first selected at)
+    int8_t term;    // Es[s]: 0 not ended, +1 / -1 ranked outcome (:78-83)
+    u8 flags;       // bit 0 expanded (s in Ps), bit 1 uniform-fallback prior (:93-100), bits 2-3 kind of term
+    u32 pad;
+    double norm;    // np.sum(Ps[s]) that renormalises the masked prior (:90-92), or the fallback's sum (:100)
 };
+#define HF_EXPANDED 1u
+#define HF_FALLBACK 2u
+__host__ __device__ inline u32 hdr_term_kind(const NodeHdr &h) { return (h.flags >> 2) & 3u; }
 
 struct DP {  // device view of a context, passed by value to every kernel
-    int W, H, N, A, G, sims, node_cap, edge_cap, table_cap, KW, RW, RMW, move_rule;
+    int W, H, N, A, G, sims, node_cap, edge_cap, vis_cap, table_cap, KW, RW, RMW, move_rule;
     int step_cap;  // max simulations a slot runs in one k_search launch (0 = until it needs the evaluator)
     u32 magicW;  // a / W == (a * magicW) >> 20 for a < 8192
     double cpuct;
@@ -68,12 +75,12 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *total_area, *max_h;
     double *bl;     // R2 threshold snapshot taken when the episode began
     int *has_buf;
-    u32 *root, *n_nodes, *n_edges;
+    u32 *root, *n_nodes, *n_edges, *n_vis;
     int *phase, *sims_done, *moves;
     u64 *episode;
     u32 *leaf_node;
     int *path_len;
-    u32 *path_edge, *path_node;  // [G][N]
+    u32 *path_edge, *path_node;  // [G][N]  (visited-entry index, node) per level
     int *game_row;
     int *last_outcome;
     double *last_score;
@@ -84,9 +91,13 @@ struct DP {  // device view of a context, passed by value to every kernel
     // arenas
     NodeHdr *hdr;   // [G][node_cap]
     u32 *key;       // [G][node_cap][KW]
-    double *eP, *eQ;  // [G][edge_cap]
-    u32 *eN, *eChild;
-    u16 *eAct;
+    u16 *pAct;      // [G][edge_cap]  legal moves of every node, ascending action
+    float *pPi;     // [G][edge_cap]  evaluator probability of that move (NNet.predict's pi, float32)
+    u16 *vIdx;      // [G][vis_cap]   visited edges: index into the node's legal-move run
+    u32 *vN;        //                Nsa (low 30 bits) | kind of Q (top 2 bits)
+    double *vQ;     //                Qsa
+    double *vP;     //                Ps[s][a] = float64(pi) / norm
+    u32 *vChild;    //                child node id (NONE32 until first traversed)
     u64 *table;     // [G][table_cap]  (tag << 32) | (node id + 1), 0 = empty
     // NumPy pairwise-sum plan over A elements
     int n_leaves;
@@ -194,11 +205,9 @@ __device__ __forceinline__ bool move_is_legal(row_t myrow, int H, int W, int j, 
 }
 
 struct ValidSink {  // where gen_valid_moves puts its result
-    u16 *act;       // edge action array (or null)
-    double *eP, *eQ;
-    u32 *eN, *eChild;
+    u16 *act;       // compact legal-move list (or null)
     u8 *mask;       // dense 0/1 mask of A bytes (or null)
-    int cap;        // edges available
+    int cap;        // list entries available
 };
 
 // BinPackingGame.getValidMoves (BinPackingGame.py:78-92): lanes stride the action space a = item*W + j,
@@ -229,14 +238,7 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
         if (sink.mask && a < p.A) sink.mask[a] = ok ? 1 : 0;
         if (sink.act) {
             if (nv + cnt > sink.cap) return -1;
-            if (ok) {
-                int e = nv + __popcll(m & lanes_below());
-                sink.act[e] = (u16)a;
-                sink.eP[e] = 0.0;
-                sink.eQ[e] = 0.0;
-                sink.eN[e] = 0u;
-                sink.eChild[e] = NONE32;
-            }
+            if (ok) sink.act[nv + __popcll(m & lanes_below())] = (u16)a;
         }
         nv += cnt;
     }
@@ -327,27 +329,31 @@ template <typename row_t> struct Tree {
     int g;
     NodeHdr *hdr;
     u32 *key;
-    double *eP, *eQ;
-    u32 *eN, *eChild;
-    u16 *eAct;
+    u16 *pAct;
+    float *pPi;
+    u16 *vIdx;
+    u32 *vN, *vChild;
+    double *vQ, *vP;
     u64 *table;
     const u8 *wh;
-    u32 n_nodes, n_edges;
+    u32 n_nodes, n_edges, n_vis;
     u64 c_probes, c_keybytes, c_nodes;
 
     __device__ Tree(const DP &p_, int g_) : p(p_), g(g_) {
         hdr = p.hdr + (size_t)g * p.node_cap;
         key = p.key + (size_t)g * p.node_cap * p.KW;
-        size_t eb = (size_t)g * p.edge_cap;
-        eP = p.eP + eb; eQ = p.eQ + eb; eN = p.eN + eb; eChild = p.eChild + eb; eAct = p.eAct + eb;
+        size_t eb = (size_t)g * p.edge_cap, vb = (size_t)g * p.vis_cap;
+        pAct = p.pAct + eb; pPi = p.pPi + eb;
+        vIdx = p.vIdx + vb; vN = p.vN + vb; vQ = p.vQ + vb; vP = p.vP + vb; vChild = p.vChild + vb;
         table = p.table + (size_t)g * p.table_cap;
         wh = p.item_wh + (size_t)g * p.N * 2;
         n_nodes = p.n_nodes[g];
         n_edges = p.n_edges[g];
+        n_vis = p.n_vis[g];
         c_probes = c_keybytes = c_nodes = 0;
     }
     __device__ void store_sizes() {
-        if (lane_id() == 0) { p.n_nodes[g] = n_nodes; p.n_edges[g] = n_edges; }
+        if (lane_id() == 0) { p.n_nodes[g] = n_nodes; p.n_edges[g] = n_edges; p.n_vis[g] = n_vis; }
     }
 
     // key of a node -> lane-resident rows + uniform remaining words
@@ -406,7 +412,7 @@ template <typename row_t> struct Tree {
     }
     // A state seen for the first time: the Es / Vs part of MCTS.search (MCTS_bpp.py:78-79 getGameEnded ->
     // has_valid_moves / getRankedReward; :88 getValidMoves).  Allocates the node, stores its key, its legal
-    // moves as an edge run (priors are filled in by the commit kernel after the evaluator ran) or its
+    // moves as a run of actions (their priors are filled in by the commit kernel after the evaluator ran) or its
     // terminal value.  Returns the node id or NONE32 on arena overflow.
     __device__ u32 materialize(row_t myrow, u64 rem0, u64 rem1, u64 h, u32 insert_slot) {
         if (n_nodes >= (u32)p.node_cap || insert_slot == NONE32) {
@@ -416,19 +422,19 @@ template <typename row_t> struct Tree {
         const u32 id = n_nodes;
         store_key(id, myrow, rem0, rem1);
         ValidSink sink;
-        sink.act = eAct + n_edges; sink.eP = eP + n_edges; sink.eQ = eQ + n_edges; sink.eN = eN + n_edges;
-        sink.eChild = eChild + n_edges; sink.mask = nullptr; sink.cap = p.edge_cap - (int)n_edges;
+        sink.act = pAct + n_edges; sink.mask = nullptr; sink.cap = p.edge_cap - (int)n_edges;
         int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
         if (nv < 0) {
             if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
             return NONE32;
         }
         NodeHdr hd;
-        hd.ns = 0; hd.edge_off = n_edges; hd.n_valid = (u32)nv; hd.term = 0; hd.term_kind = RP_KIND_WEAK; hd.expanded = 0; hd.pad = 0;
+        hd.ns = 0; hd.prior_off = n_edges; hd.vis_off = 0; hd.n_valid = (u16)nv; hd.vis_n = 0; hd.vis_cap = 0; hd.term = 0;
+        hd.flags = (u8)(RP_KIND_WEAK << 2); hd.pad = 0; hd.norm = 0.0;
         if (nv == 0) {  // no legal move: game over (BinPackingGame.py:112-114)
             double r;
             int e = ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
-            if (e == 2) { e = tie_value<row_t>(myrow, p.H, p.N, rem0, rem1, p.tie_salt); hd.term_kind = RP_KIND_F64; }
+            if (e == 2) { e = tie_value<row_t>(myrow, p.H, p.N, rem0, rem1, p.tie_salt); hd.flags = (u8)(RP_KIND_F64 << 2); }
             hd.term = (int8_t)e;
         }
         if (lane_id() == 0) {
@@ -448,48 +454,112 @@ template <typename row_t> struct Tree {
         if (id == NONE32) { id = materialize(myrow, rem0, rem1, h, slot); *was_new = true; }
         return id;
     }
-    // child state of (node, edge): BinPackingGame.getNextState (BinPackingGame.py:58-76)
-    __device__ u32 resolve_child(u32 node, u32 e, bool *was_new) {
+    // child state of (node, action): BinPackingGame.getNextState (BinPackingGame.py:58-76); links visited entry e to it
+    __device__ u32 resolve_child(u32 node, u32 e, int a, bool *was_new) {
         row_t myrow; u64 rem0, rem1;
         load_key(node, myrow, rem0, rem1);
-        int a = eAct[e];
         int i = (int)(((u32)a * p.magicW) >> 20), j = a - i * p.W;
         myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, wh[2 * i], wh[2 * i + 1]);
         if (i < 64) rem0 &= ~(1ull << i); else rem1 &= ~(1ull << (i - 64));
         u32 child = find_or_materialize(myrow, rem0, rem1, was_new);
-        if (lane_id() == 0 && child != NONE32) eChild[e] = child;
+        if (lane_id() == 0 && child != NONE32 && e != NONE32) vChild[e] = child;
         return child;
     }
-    // PUCT argmax over the node's edge run (MCTS_bpp.py:106-121), float64, strict '>' in ascending action
-    // order == maximum with the lowest edge index.  Returns the edge index (absolute in the slot arrays).
-    __device__ u32 select_edge(const NodeHdr &hd) const {
+    // Ps[s][a] of a legal move from the stored float32 pi and the node's normaliser (MCTS_bpp.py:89-100)
+    static __device__ __forceinline__ double prior_of(float pi, double norm, bool fallback) {
+        double x = (double)pi * 1.0;
+        return fallback ? (x + 1.0) / norm : x / norm;
+    }
+    // The visited-edge block of a node grows by doubling inside the slot's arena (old blocks are abandoned: at most the
+    // live size again).  Returns false on arena overflow.
+    __device__ bool grow_visited(u32 node, NodeHdr &hd) {
+        u32 cap = hd.vis_cap ? 2u * hd.vis_cap : 2u;
+        if (cap > hd.n_valid) cap = hd.n_valid;
+        if (n_vis + cap > (u32)p.vis_cap) {
+            if (lane_id() == 0) set_error(p, ERR_VIS_CAP);
+            return false;
+        }
+        const u32 dst = n_vis;
+        for (u32 j = lane_id(); j < hd.vis_n; j += 64) {
+            u32 s = hd.vis_off + j, d = dst + j;
+            vIdx[d] = vIdx[s]; vN[d] = vN[s]; vQ[d] = vQ[s]; vP[d] = vP[s]; vChild[d] = vChild[s];
+        }
+        n_vis += cap;
+        hd.vis_off = dst; hd.vis_cap = (u16)cap;
+        if (lane_id() == 0) { hdr[node].vis_off = dst; hdr[node].vis_cap = (u16)cap; }
+        wave_sync();
+        return true;
+    }
+    // appends the visited entry of legal move k (Nsa = 0 until the backup reaches it); returns its index or NONE32
+    __device__ u32 append_visited(u32 node, NodeHdr &hd, u32 k) {
+        if (hd.vis_n == hd.vis_cap && !grow_visited(node, hd)) return NONE32;
+        const u32 e = hd.vis_off + hd.vis_n;
+        if (lane_id() == 0) {
+            vIdx[e] = (u16)k; vN[e] = 0u; vQ[e] = 0.0; vChild[e] = NONE32;
+            vP[e] = prior_of(pPi[hd.prior_off + k], hd.norm, (hd.flags & HF_FALLBACK) != 0);
+            hdr[node].vis_n = (u16)(hd.vis_n + 1);
+        }
+        hd.vis_n++;
+        return e;
+    }
+    // PUCT argmax (MCTS_bpp.py:106-121), float64, strict '>' in ascending action order == maximum with the lowest legal-
+    // move index.  Visited edges come from the node's block (Q + cpuct*P*sqrt(Ns)/(1+Nsa)), all others from the prior run
+    // (cpuct*P*sqrt(Ns+EPS)); an LDS bit mask tells the two apart.  Returns the visited-entry index of the chosen edge
+    // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.
+    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out) {
+        const int lane = lane_id();
         const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
         const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
+        const u32 words = ((u32)hd.n_valid + 31u) >> 5;
+        for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
+        wave_sync();
         double best_u = -INFINITY;
-        u32 best_e = NONE32;
-        for (u32 k = lane_id(); k < hd.n_valid; k += 64) {
-            u32 e = hd.edge_off + k;
-            double cp = p.cpuct * eP[e];
-            u32 nn = eN[e] & NSA_MASK;
-            double u = nn ? eQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
-            if (u > best_u) { best_u = u; best_e = e; }
+        u32 best_k = NONE32, best_e = NONE32;
+        for (u32 j = lane; j < hd.vis_n; j += 64) {
+            u32 e = hd.vis_off + j, k = vIdx[e];
+            atomicOr(&vmask[k >> 5], 1u << (k & 31));
+            u32 nn = vN[e] & NSA_MASK;
+            double cp = p.cpuct * vP[e];
+            double u = nn ? vQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
+            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; }
+        }
+        wave_sync();
+        const bool fb = (hd.flags & HF_FALLBACK) != 0;
+        for (u32 k = lane; k < hd.n_valid; k += 64) {
+            if ((vmask[k >> 5] >> (k & 31)) & 1u) continue;
+            double u = (p.cpuct * prior_of(pPi[hd.prior_off + k], hd.norm, fb)) * s_new;
+            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = NONE32; }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             double ou = __shfl_xor(best_u, o);
-            u32 oe = __shfl_xor(best_e, o);
-            if (ou > best_u || (ou == best_u && oe < best_e)) { best_u = ou; best_e = oe; }
+            u32 ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o);
+            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; }
         }
+        wave_sync();
+        k_out = best_k;
+        if (best_k == NONE32) return NONE32;
+        if (best_e == NONE32) best_e = append_visited(node, hd, best_k);
         return best_e;
+    }
+    // visited entry of legal move k, or NONE32
+    __device__ u32 find_visited(const NodeHdr &hd, u32 k) const {
+        u32 found = NONE32;
+        for (u32 jb = 0; jb < hd.vis_n; jb += 64) {
+            u32 j = jb + lane_id();
+            u64 b = __ballot(j < hd.vis_n && vIdx[hd.vis_off + (j < hd.vis_n ? j : 0)] == (u16)k);
+            if (b) { found = hd.vis_off + jb + (__ffsll((long long)b) - 1); break; }
+        }
+        return found;
     }
     // one lane per path entry (MCTS_bpp.py:130-138)
     __device__ void backup_entry(u32 node, u32 e, double v, u32 vkind) {
-        u32 nn = eN[e];
+        u32 nn = vN[e];
         u32 cnt = nn & NSA_MASK, kind = nn >> 30;
-        double q = eQ[e];
+        double q = vQ[e];
         q_update(q, kind, cnt, v, vkind);
-        eQ[e] = q;
-        eN[e] = (kind << 30) | (cnt + 1u);
+        vQ[e] = q;
+        vN[e] = (kind << 30) | (cnt + 1u);
         hdr[node].ns += 1u;
     }
 };
@@ -508,56 +578,66 @@ template <typename row_t>
 __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, u64 *c) {
     NodeHdr hd = t.hdr[root];
     const int lane = lane_id();
-    u32 chosen = NONE32;
+    u32 chosen = NONE32;  // visited entry of the move that is played
+    int free_action = -1;  // legal move played from a root the search never expanded (no statistics to keep)
     if (action >= 0) {
-        for (u32 k = lane; k < hd.n_valid + ((64 - hd.n_valid % 64) % 64); k += 64) {
-            bool m = k < hd.n_valid && t.eAct[hd.edge_off + k] == (u16)action;
-            u64 b = __ballot(m);
-            if (b) { chosen = hd.edge_off + (k - lane) + (__ffsll((long long)b) - 1); break; }
+        u32 ksel = NONE32;
+        for (u32 kb = 0; kb < hd.n_valid; kb += 64) {
+            u32 k = kb + lane;
+            u64 b = __ballot(k < hd.n_valid && t.pAct[hd.prior_off + (k < hd.n_valid ? k : 0)] == (u16)action);
+            if (b) { ksel = kb + (__ffsll((long long)b) - 1); break; }
         }
-    } else if (p.move_rule == RP_MOVE_ARGMAX_FIRST) {
-        u32 best_n = 0, best_e = NONE32;
-        for (u32 k = lane; k < hd.n_valid; k += 64) {
-            u32 n = t.eN[hd.edge_off + k] & NSA_MASK;
-            if (n > best_n) { best_n = n; best_e = hd.edge_off + k; }
+        if (ksel != NONE32 && (hd.flags & HF_EXPANDED)) {
+            chosen = t.find_visited(hd, ksel);
+            if (chosen == NONE32) chosen = t.append_visited(root, hd, ksel);  // a legal move the search never tried
+        } else if (ksel != NONE32) {
+            free_action = action;
+        }
+    } else if (p.move_rule == RP_MOVE_ARGMAX_FIRST) {  // most visited, lowest action among equals
+        u32 best_n = 0, best_k = NONE32, best_e = NONE32;
+        for (u32 j = lane; j < hd.vis_n; j += 64) {
+            u32 e = hd.vis_off + j, n = t.vN[e] & NSA_MASK, k = t.vIdx[e];
+            if (n > best_n || (n == best_n && n > 0 && k < best_k)) { best_n = n; best_k = k; best_e = e; }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            u32 on = __shfl_xor(best_n, o), oe = __shfl_xor(best_e, o);
-            if (on > best_n || (on == best_n && oe < best_e)) { best_n = on; best_e = oe; }
+            u32 on = __shfl_xor(best_n, o), ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o);
+            if (on > best_n || (on == best_n && ok < best_k)) { best_n = on; best_k = ok; best_e = oe; }
         }
         chosen = best_n ? best_e : NONE32;
-    } else {  // RP_MOVE_SAMPLE: a ~ counts, inverse CDF over the edge run in action order
+    } else {  // RP_MOVE_SAMPLE: a ~ counts; inverse CDF in ascending action order over the (unordered) visited block
         u64 total = 0;
-        for (u32 k = lane; k < hd.n_valid; k += 64) total += t.eN[hd.edge_off + k] & NSA_MASK;
+        for (u32 j = lane; j < hd.vis_n; j += 64) total += t.vN[hd.vis_off + j] & NSA_MASK;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
         if (total) {
             u64 x = sample_u64(p.seed, p.episode[g], (u64)p.moves[g]);
-            u64 r = __umul64hi(x, total), acc = 0;
-            for (u32 kb = 0; kb < hd.n_valid && chosen == NONE32; kb += 64) {
-                u32 k = kb + lane;
-                u64 n = k < hd.n_valid ? (u64)(t.eN[hd.edge_off + k] & NSA_MASK) : 0ull;
-                u64 pre = n;  // inclusive prefix sum over the 64 lanes
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    u64 up = __shfl_up(pre, o);
-                    if (lane >= o) pre += up;
+            u64 r = __umul64hi(x, total);
+            for (u32 jb = 0; jb < hd.vis_n && chosen == NONE32; jb += 64) {
+                u32 j = jb + lane;
+                bool act = j < hd.vis_n;
+                u32 e = hd.vis_off + (act ? j : 0);
+                u32 k = t.vIdx[e];
+                u64 n = act ? (u64)(t.vN[e] & NSA_MASK) : 0ull, below = 0;
+                for (u32 i = 0; i < hd.vis_n; ++i) {  // counts of all lower actions (uniform loads)
+                    u32 e2 = hd.vis_off + i;
+                    if (t.vIdx[e2] < k) below += t.vN[e2] & NSA_MASK;
                 }
-                u64 b = __ballot(acc + pre > r);
-                if (b) chosen = hd.edge_off + kb + (__ffsll((long long)b) - 1);
-                acc += __shfl(pre, 63);
+                u64 b = __ballot(act && n > 0 && below <= r && r < below + n);
+                if (b) chosen = hd.vis_off + jb + (__ffsll((long long)b) - 1);
             }
         }
     }
-    if (chosen == NONE32) {
+    if (chosen == NONE32 && free_action < 0) {
         if (lane == 0) { set_error(p, ERR_BAD_ACTION); p.phase[g] = RP_PHASE_FAILED; }
         return;
     }
-    u32 child = t.eChild[chosen];
+    wave_sync();
+    const int chosen_action = chosen != NONE32 ? (int)t.pAct[hd.prior_off + t.vIdx[chosen]] : free_action;
+    u32 child = chosen != NONE32 ? t.vChild[chosen] : NONE32;
     if (child == NONE32) {
         bool was_new;
-        child = t.resolve_child(root, chosen, &was_new);
+        child = t.resolve_child(root, chosen, chosen_action, &was_new);
         wave_sync();
         if (child == NONE32) { if (lane == 0) p.phase[g] = RP_PHASE_FAILED; return; }
     }
@@ -576,9 +656,10 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
             for (int a = lane; a < p.A; a += 64) ec[a] = 0u;
             wave_sync();
             if (p.onehot_examples) {
-                if (lane == 0) ec[t.eAct[chosen]] = 1u;
+                if (lane == 0) ec[chosen_action] = 1u;
             } else {
-                for (u32 q = lane; q < hd.n_valid; q += 64) ec[t.eAct[hd.edge_off + q]] = t.eN[hd.edge_off + q] & NSA_MASK;
+                for (u32 q = lane; q < hd.vis_n; q += 64)  // hd may have grown by one entry above: re-read the header's view
+                    ec[t.pAct[hd.prior_off + t.vIdx[hd.vis_off + q]]] = t.vN[hd.vis_off + q] & NSA_MASK;
             }
             if (lane == 0) { p.ex_value[idx] = 0; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
         } else if (lane == 0) {
@@ -641,7 +722,7 @@ __device__ void restart_slot(const DP &p, Tree<row_t> &t, int g, u32 &root, u64 
         p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;
         p.last_outcome[g] = 0; p.last_score[g] = 0.0;
     }
-    t.n_nodes = 0; t.n_edges = 0;
+    t.n_nodes = 0; t.n_edges = 0; t.n_vis = 0;
     wave_sync();
     bool was_new;
     row_t myrow = 0;
@@ -659,6 +740,8 @@ __device__ void restart_slot(const DP &p, Tree<row_t> &t, int g, u32 &root, u64 
 // needs the evaluator or the move's budget is spent.
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
+    __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    u32 *vmask = s_vmask[threadIdx.x >> 6];
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (g >= p.G) return;
     int phase = p.phase[g];
@@ -701,20 +784,22 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
         for (;;) {
             NodeHdr hd = t.hdr[node];
             if (hd.term != 0) {  // :81-83
-                v = (double)hd.term; vkind = hd.term_kind; c[CNT_TERMINAL]++;
+                v = (double)hd.term; vkind = hdr_term_kind(hd); c[CNT_TERMINAL]++;
                 break;
             }
-            if (!hd.expanded) { need_eval = true; break; }  // :85 leaf
-            u32 e = t.select_edge(hd);
+            if (!(hd.flags & HF_EXPANDED)) { need_eval = true; break; }  // :85 leaf
+            u32 ksel;
+            u32 e = t.select_edge(node, hd, vmask, ksel);
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
             if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
             else if (lane == depth - 64) { pe1 = e; pn1 = node; }
             depth++;
             c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid;
-            u32 child = t.eChild[e];
+            wave_sync();
+            u32 child = t.vChild[e];
             if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
                 bool was_new;
-                child = t.resolve_child(node, e, &was_new);
+                child = t.resolve_child(node, e, t.pAct[hd.prior_off + ksel], &was_new);
                 if (child == NONE32) { failed = true; break; }
                 if (!was_new) c[CNT_TRANSPOSE]++;
                 wave_sync();
@@ -798,21 +883,20 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
     return total;
 }
 
-// fills P for one node from the evaluator's pi (MCTS_bpp.py:87-100)
-__device__ void masked_prior(const DP &p, const float *pi, const u16 *act, double *P, u32 n_valid, u32 *vmask, double *sleaf) {
+// Normaliser of one node's masked prior from the evaluator's pi (MCTS_bpp.py:88-100): np.sum(pi * valids) if that is
+// positive, else the sum of the uniform fallback pi * valids + valids.  The legal moves' float32 pi go to `pi_out`.
+__device__ double masked_prior(const DP &p, const float *pi, const u16 *act, float *pi_out, u32 n_valid, u32 *vmask, double *sleaf,
+                               bool *fallback) {
     const int lane = lane_id();
     const int words = (p.A + 31) >> 5;
     for (int w = lane; w < words; w += 64) vmask[w] = 0u;
     wave_sync();
-    for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); }
+    for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); pi_out[k] = pi[a]; }
     wave_sync();
     double s = numpy_masked_sum(p, pi, vmask, sleaf, 0);
-    if (s > 0) {  // :91-92
-        for (u32 k = lane; k < n_valid; k += 64) P[k] = ((double)pi[act[k]] * 1.0) / s;
-    } else {  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
-        double s2 = numpy_masked_sum(p, pi, vmask, sleaf, 1);
-        for (u32 k = lane; k < n_valid; k += 64) P[k] = ((double)pi[act[k]] * 1.0 + 1.0) / s2;
-    }
+    *fallback = !(s > 0);                                      // :91
+    if (*fallback) s = numpy_masked_sum(p, pi, vmask, sleaf, 1);  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
+    return s;
 }
 
 // Expansion + backup for the waiting leaves (MCTS_bpp.py:87-104 then :130-139 up the path).
@@ -826,8 +910,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     Tree<row_t> t(p, g);
     const u32 node = p.leaf_node[g];
     NodeHdr hd = t.hdr[node];
-    masked_prior(p, pi + (size_t)b * p.A, t.eAct + hd.edge_off, t.eP + hd.edge_off, hd.n_valid, s_mask[wv], s_leaf[wv]);
-    if (lane == 0) { hd.expanded = 1; hd.ns = 0; t.hdr[node] = hd; }  // Vs[s] = valids; Ns[s] = 0 (:102-103)
+    bool fb;
+    double norm = masked_prior(p, pi + (size_t)b * p.A, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], &fb);
+    if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
+        hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
+        t.hdr[node] = hd;
+    }
     const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
     const int depth = p.path_len[g];
     const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
@@ -903,7 +991,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
         u64 *tab = p.table + (size_t)g * p.table_cap;
         for (int s = lane; s < p.table_cap; s += 64) tab[s] = 0ull;
         if (lane == 0) {
-            p.n_nodes[g] = 0; p.n_edges[g] = 0; p.moves[g] = 0;
+            p.n_nodes[g] = 0; p.n_edges[g] = 0; p.n_vis[g] = 0; p.moves[g] = 0;
             p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;  // rewards_list snapshot for this episode
             p.last_outcome[g] = 0; p.last_score[g] = 0.0;
         }
@@ -958,8 +1046,9 @@ __global__ void k_root_counts(DP p, int first, int count, u32 *out) {
     u32 root = p.root[g];
     if (root == NONE32) return;
     NodeHdr hd = p.hdr[(size_t)g * p.node_cap + root];
-    size_t eb = (size_t)g * p.edge_cap + hd.edge_off;
-    for (u32 e = lane; e < hd.n_valid; e += 64) o[p.eAct[eb + e]] = p.eN[eb + e] & NSA_MASK;
+    const u16 *act = p.pAct + (size_t)g * p.edge_cap + hd.prior_off;
+    size_t vb = (size_t)g * p.vis_cap + hd.vis_off;
+    for (u32 j = lane; j < hd.vis_n; j += 64) o[act[p.vIdx[vb + j]]] = p.vN[vb + j] & NSA_MASK;
 }
 
 template <typename row_t>
@@ -1010,7 +1099,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     ValidSink sink;
-    sink.act = nullptr; sink.eP = sink.eQ = nullptr; sink.eN = sink.eChild = nullptr; sink.mask = mask + b * p.A; sink.cap = 0;
+    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     if (nvalid && lane_id() == 0) nvalid[b] = nv;
 }
@@ -1049,7 +1138,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long 
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     ValidSink sink;
-    sink.act = nullptr; sink.eP = sink.eQ = nullptr; sink.eN = sink.eChild = nullptr; sink.mask = nullptr; sink.cap = 0;
+    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     double r = 0.0;
     int e = 0;
@@ -1076,13 +1165,15 @@ __global__ void k_selftest_q(long long n, const double *q, const u8 *qk, const u
         qo[i] = x; qko[i] = (u8)k;
     }
 }
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, long long B, const float *pi, const u8 *valid, double *out, u16 *act_scratch) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, long long B, const float *pi, const u8 *valid, double *out, u16 *act_scratch,
+                                                                          float *pi_scratch) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
     const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     u16 *act = act_scratch + b * p.A;
+    float *pc = pi_scratch + b * p.A;
     double *o = out + b * p.A;
     int nv = 0;
     for (int base = 0; base < p.A; base += 64) {  // compact the valid actions in order
@@ -1094,13 +1185,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
         nv += __popcll(m);
     }
     wave_sync();
-    // masked_prior writes compact priors P[k], k < nv, into the front of the (zeroed) dense row ...
-    masked_prior(p, pi + b * p.A, act, o, (u32)nv, s_mask[wv], s_leaf[wv]);
+    bool fb;
+    double norm = masked_prior(p, pi + b * p.A, act, pc, (u32)nv, s_mask[wv], s_leaf[wv], &fb);
     wave_sync();
-    // ... which are then expanded in place from the back (act[k] >= k always)
-    for (int k = nv - 1; k >= 0; --k) {
-        if (lane == 0) { double x = o[k]; o[k] = 0.0; o[act[k]] = x; }
-    }
+    for (int k = lane; k < nv; k += 64) o[act[k]] = Tree<u32>::prior_of(pc[k], norm, fb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1161,11 +1249,12 @@ static int check_device_error(rp_ctx *ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (e == 0) return RP_OK;
     (void)hipMemsetAsync(ctx->d.error, 0, sizeof(int), ctx->stream);
-    static const char *names[] = {"", "node arena overflow (raise node_cap)", "edge arena overflow (raise edge_cap)",
-                                  "transposition table full", "action is not a legal move of the root", "search path broken",
-                                  "finished-episode ring overflow", "replay buffer full (raise max_examples)"};
+    static const char *names[] = {"", "node arena overflow (raise node_cap)", "legal-move arena overflow (raise edge_cap)",
+                                  "transposition table full", "action is not a legal move of the (expanded) root", "search path broken",
+                                  "finished-episode ring overflow", "replay buffer full (raise max_examples)",
+                                  "visited-edge arena overflow (raise vis_cap)"};
     int code = (e == ERR_BAD_ACTION) ? RP_ERR_ASSERT : (e == ERR_PATH ? RP_ERR_STATE : RP_ERR_CAPACITY);
-    return fail(ctx, code, "device error %d: %s", e, e < 8 ? names[e] : "?");
+    return fail(ctx, code, "device error %d: %s", e, e < 9 ? names[e] : "?");
 }
 
 // leaves and combine schedule of NumPy's pairwise sum over n elements (oracle: pairwise_sum)
@@ -1221,6 +1310,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.cpuct = cfg->cpuct; d.seed = cfg->seed; d.tie_salt = cfg->tie_salt; d.move_rule = cfg->move_rule;
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (cfg->N + 1) + 2;
     d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 96) + d.A;
+    d.vis_cap = cfg->vis_cap > 0 ? cfg->vis_cap : 6 * d.node_cap + 64;
     int tc = 64;
     while (tc < 2 * d.node_cap) tc *= 2;
     d.table_cap = tc;
@@ -1236,12 +1326,13 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     int rc = RP_OK;
     auto A_ = [&](auto &ptr, size_t n) { if (rc == RP_OK) rc = dev_alloc(ctx, &ptr, n); };
     A_(d.item_wh, G * N * 2); A_(d.total_area, G); A_(d.max_h, G); A_(d.bl, G); A_(d.has_buf, G);
-    A_(d.root, G); A_(d.n_nodes, G); A_(d.n_edges, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
+    A_(d.root, G); A_(d.n_nodes, G); A_(d.n_edges, G); A_(d.n_vis, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
     A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
     A_(d.last_outcome, G); A_(d.last_score, G); A_(d.last_v, G); A_(d.last_vkind, G);
     A_(d.eval_count, 1); A_(d.eval_slot, G);
     A_(d.hdr, G * d.node_cap); A_(d.key, G * d.node_cap * d.KW);
-    A_(d.eP, G * d.edge_cap); A_(d.eQ, G * d.edge_cap); A_(d.eN, G * d.edge_cap); A_(d.eChild, G * d.edge_cap); A_(d.eAct, G * d.edge_cap);
+    A_(d.pAct, G * d.edge_cap); A_(d.pPi, G * d.edge_cap);
+    A_(d.vIdx, G * d.vis_cap); A_(d.vN, G * d.vis_cap); A_(d.vQ, G * d.vis_cap); A_(d.vP, G * d.vis_cap); A_(d.vChild, G * d.vis_cap);
     A_(d.table, G * d.table_cap);
     A_(d.g_bl, 1); A_(d.g_has_buf, 1); A_(d.counters, CNT_N); A_(d.error, 1);
     d.fin_cap = (int)std::max<size_t>(4 * G, 1024);
@@ -1263,7 +1354,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, rc, "rp_create: %s (needs about %.1f GiB of HBM)", msg.c_str(),
-                    (double)(G * ((size_t)d.node_cap * (16 + 4 * d.KW) + (size_t)d.edge_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
+                    (double)(G * ((size_t)d.node_cap * (32 + 4 * d.KW) + (size_t)d.edge_cap * 6 + (size_t)d.vis_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
     }
     d.n_leaves = (int)L;
     d.leaf_lo = plan; d.leaf_n = plan + L; d.sched_dst = plan + 2 * L; d.sched_src = plan + 2 * L + S;
@@ -1681,24 +1772,42 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
     int nn = 0, ne = 0;
     int rc = rp_tree_size(ctx, slot, &nn, &ne);
     if (rc != RP_OK) return rc;
+    int nv = 0;
+    HIPCHK(ctx, hipMemcpy(&nv, d.n_vis + slot, sizeof(int), hipMemcpyDeviceToHost));
     std::vector<NodeHdr> hdr(nn);
-    std::vector<u32> key((size_t)nn * d.KW), eN(ne), eC(ne);
+    std::vector<u32> key((size_t)nn * d.KW), vN(nv), vC(nv);
+    std::vector<u16> vI(nv);
+    std::vector<float> pi(ne);
+    std::vector<double> vQ(nv), vP(nv);
     HIPCHK(ctx, hipMemcpy(hdr.data(), d.hdr + (size_t)slot * d.node_cap, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(key.data(), d.key + (size_t)slot * d.node_cap * d.KW, (size_t)nn * d.KW * 4, hipMemcpyDeviceToHost));
-    size_t eb = (size_t)slot * d.edge_cap;
-    HIPCHK(ctx, hipMemcpy(edge_action, d.eAct + eb, (size_t)ne * 2, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(edge_p, d.eP + eb, (size_t)ne * 8, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(edge_q, d.eQ + eb, (size_t)ne * 8, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(eN.data(), d.eN + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(edge_child, d.eChild + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
-    for (int e = 0; e < ne; ++e) { edge_nsa[e] = eN[e] & NSA_MASK; edge_q_kind[e] = (u8)(eN[e] >> 30); }
+    size_t eb = (size_t)slot * d.edge_cap, vb = (size_t)slot * d.vis_cap;
+    HIPCHK(ctx, hipMemcpy(edge_action, d.pAct + eb, (size_t)ne * 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(pi.data(), d.pPi + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vI.data(), d.vIdx + vb, (size_t)nv * 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vN.data(), d.vN + vb, (size_t)nv * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vC.data(), d.vChild + vb, (size_t)nv * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vQ.data(), d.vQ + vb, (size_t)nv * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vP.data(), d.vP + vb, (size_t)nv * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) {
+        const NodeHdr &h = hdr[i];
         const u32 *k = key.data() + (size_t)i * d.KW;
         for (int r = 0; r < d.H; ++r) node_rows[(size_t)i * d.H + r] = ctx->row64 ? ((const u64 *)k)[r] : (u64)k[r];
         const u32 *rw = k + d.H * d.RW;
         for (int it = 0; it < d.N; ++it) node_remaining[(size_t)i * d.N + it] = (u8)((rw[it >> 5] >> (it & 31)) & 1u);
-        node_term[i] = hdr[i].term; node_term_kind[i] = hdr[i].term_kind; node_expanded[i] = hdr[i].expanded;
-        node_ns[i] = hdr[i].ns; node_edge_off[i] = hdr[i].edge_off; node_n_valid[i] = hdr[i].n_valid;
+        node_term[i] = h.term; node_term_kind[i] = (u8)hdr_term_kind(h); node_expanded[i] = (h.flags & HF_EXPANDED) ? 1 : 0;
+        node_ns[i] = h.ns; node_edge_off[i] = h.prior_off; node_n_valid[i] = h.n_valid;
+        // dense per-legal-move view: the prior as the search would compute it, statistics only where an edge was visited
+        for (u32 e = h.prior_off; e < h.prior_off + h.n_valid; ++e) {
+            double x = (double)pi[e] * 1.0;
+            edge_p[e] = !(h.flags & HF_EXPANDED) ? 0.0 : ((h.flags & HF_FALLBACK) ? (x + 1.0) / h.norm : x / h.norm);
+            edge_q[e] = 0.0; edge_nsa[e] = 0; edge_q_kind[e] = 0; edge_child[e] = NONE32;
+        }
+        for (u32 j = 0; j < h.vis_n; ++j) {
+            u32 v = h.vis_off + j, e = h.prior_off + vI[v];
+            if (edge_p[e] != vP[v]) return fail(ctx, RP_ERR_STATE, "rp_dump_tree: stored prior of a visited edge differs from pi / norm");
+            edge_q[e] = vQ[v]; edge_nsa[e] = vN[v] & NSA_MASK; edge_q_kind[e] = (u8)(vN[v] >> 30); edge_child[e] = vC[v];
+        }
     }
     return RP_OK;
 }
@@ -1746,8 +1855,9 @@ extern "C" int rp_selftest_masked_prior(rp_ctx *ctx, int64_t B, const float *pi,
     u8 *dva = s.up(valid, (size_t)B * d.A); NEED(dva);
     double *dout = s.up((const double *)nullptr, (size_t)B * d.A); NEED(dout);
     u16 *dact = s.up((const u16 *)nullptr, (size_t)B * d.A); NEED(dact);
+    float *dpc = s.up((const float *)nullptr, (size_t)B * d.A); NEED(dpc);
     hipLaunchKernelGGL(k_selftest_prior, dim3(grid_for(B)), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, (long long)B, (const float *)dpi,
-                       (const u8 *)dva, dout, dact);
+                       (const u8 *)dva, dout, dact, dpc);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(p_out, dout, (size_t)B * d.A * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
