@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=72, help="edge arena = node arena x this")
     ap.add_argument("--groups", type=int, default=2, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
     ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
+    ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -186,7 +187,7 @@ def main():
     pool = a.pool or 2 * a.games
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
-                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap)
+                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)
@@ -206,8 +207,8 @@ def main():
                     with torch.cuda.stream(g0.stream):
                         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                         ev[0].record(); g0.eng.search_step(sync=False)
-                        ev[1].record(); g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
-                        ev[2].record(); pi, v = sp.nnet.predict_batch(g0.planes)
+                        ev[1].record(); g0.eng.leaf_stem(g0.stem.data_ptr(), g0.G) if g0.use_stem else g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
+                        ev[2].record(); pi, v = g0.forward(sp.nnet)
                         ev[3].record(); g0.eng.commit_eval(pi.data_ptr(), v.data_ptr())
                         ev[4].record()
                     for g in sp.groups[1:]:
@@ -286,7 +287,7 @@ def main():
                        "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
                        "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
                        "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
-        "phase_ms_per_launch": {"search": per_wave[0], "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
+        "phase_ms_per_launch": {"search": per_wave[0], "leaf_stem" if sp.use_stem else "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
         "roofline": {"kernel": "CNN evaluator (all PyTorch-ROCm kernels of one forward over the slot batch)", "bound": "mfma",
                      "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": None, "flops_per_leaf": flops_leaf, "leaves_per_launch": sp.groups[0].G},

@@ -154,6 +154,14 @@ int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out);
  * BinPackingGame.getBinItem + NNet.predict's view (BinPackingGame.py:118-120, NNet.py:77-79),
  * into caller-owned DEVICE memory (capacity_rows rows). */
 int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows);
+/* Evaluator stem on device: the network's first convolution + max-pool (BinpackingNNet.py:34,39-40:
+ * conv_seqs[0].conv 3x3 pad 1, N+1 -> 16 channels, then max_pool2d(3, stride 2, pad 1)) evaluated straight from the packed
+ * leaf states, exploiting that item planes are origin-anchored rectangles (tabulated tap sums).  rp_stem_set_weights reads
+ * the DEVICE weight [16][N+1][3][3] and bias [16] tensors and rebuilds the tables (call again after every weight update);
+ * rp_leaf_stem writes FP32 [n][16][(H+1)/2][(W+1)/2] into caller-owned DEVICE memory, the input of conv_seqs[0].res_block0.
+ * Same result as rp_leaf_planes + the two PyTorch ops up to float32 summation order. */
+int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const float *bias_dev);
+int rp_leaf_stem(rp_ctx *ctx, float *out_dev, int64_t capacity_rows);
 /* Host copy of the waiting leaves' packed states and slots (parity tests, host evaluators). */
 int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out /*[n][H]*/, uint8_t *remaining_out /*[n][N]*/,
                    int32_t *slot_out /*[n]*/, int32_t *n_out);

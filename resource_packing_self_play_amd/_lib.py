@@ -57,6 +57,8 @@ _SIGS = {
     "rp_last_values": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rp_search_step": (C.c_int, [_vp, _vp]),
     "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
+    "rp_stem_set_weights": (C.c_int, [_vp, _vp, _vp]),
+    "rp_leaf_stem": (C.c_int, [_vp, _vp, _i64]),
     "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "rp_commit_eval": (C.c_int, [_vp, _vp, _vp]),
     "rp_commit_eval_host": (C.c_int, [_vp, _vp, _vp, _i32]),
@@ -233,6 +235,12 @@ class Engine:
 
     def leaf_planes(self, dev_ptr, capacity_rows):
         self._ck(self.L.rp_leaf_planes(self.h, C.c_void_p(dev_ptr), capacity_rows))
+
+    def stem_set_weights(self, conv_w_dev_ptr, bias_dev_ptr):
+        self._ck(self.L.rp_stem_set_weights(self.h, C.c_void_p(conv_w_dev_ptr), C.c_void_p(bias_dev_ptr)))
+
+    def leaf_stem(self, dev_ptr, capacity_rows):
+        self._ck(self.L.rp_leaf_stem(self.h, C.c_void_p(dev_ptr), capacity_rows))
 
     def leaf_states(self, max_rows=None):
         max_rows = self.G if max_rows is None else max_rows

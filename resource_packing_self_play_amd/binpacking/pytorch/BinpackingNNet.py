@@ -77,6 +77,17 @@ class BinPackingNNet(nn.Module):
         x = F.relu(torch.flatten(x, start_dim=1))
         return F.relu(self.hidden_fc(x))
 
-    def forward(self, x):
-        z = self.trunk(x)
+    def heads(self, z):
         return F.log_softmax(self.logits_fc(z), dim=1), torch.tanh(self.value_fc(z))
+
+    def forward(self, x):
+        return self.heads(self.trunk(x))
+
+    def forward_from_stem(self, y):
+        """y = max_pool2d(conv_seqs[0].conv(x), 3, 2, 1), e.g. from the engine's rp_leaf_stem: the rest of the network."""
+        st0 = self.conv_seqs[0]
+        y = st0.res_block1(st0.res_block0(y))
+        for stage in self.conv_seqs[1:]:
+            y = stage(y)
+        y = F.relu(torch.flatten(y, start_dim=1))
+        return self.heads(F.relu(self.hidden_fc(y)))

@@ -47,6 +47,18 @@ class NNetWrapper(NeuralNet):
             log_pi, v = self.nnet(planes)
             return torch.exp(log_pi).contiguous(), v.reshape(-1).contiguous()
 
+    def stem_params(self):
+        """(weight [16, N+1, 3, 3], bias [16]) of the first convolution, contiguous FP32 on the device (rp_stem_set_weights)."""
+        conv = self.nnet.conv_seqs[0].conv
+        return conv.weight.detach().contiguous(), conv.bias.detach().contiguous()
+
+    def predict_from_stem(self, stem):
+        """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch."""
+        self.nnet.eval()
+        with torch.no_grad():
+            log_pi, v = self.nnet.forward_from_stem(stem)
+            return torch.exp(log_pi).contiguous(), v.reshape(-1).contiguous()
+
     # ---- training ----------------------------------------------------------------------------
     def loss_pi(self, targets, outputs):
         return -torch.sum(targets * outputs) / targets.size()[0]

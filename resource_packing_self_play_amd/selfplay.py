@@ -5,8 +5,9 @@ Every engine slot plays one episode at a time.  The slots of a GPU are split int
 own engine context, HIP stream and captured HIP graph of one simulation WAVE:
 
     rp_search_step      select / descend / terminal backups on device until each slot needs a leaf evaluated
-    rp_leaf_planes      leaf states -> FP32 NCHW planes written straight into the evaluator's input tensor
-    NNetWrapper.predict_batch   the CNN through PyTorch-ROCm (FP32)
+    rp_leaf_stem        leaf states -> first convolution + max-pool of the CNN, computed from the packed state
+                        (or rp_leaf_planes: FP32 NCHW planes for a generic evaluator)
+    NNetWrapper.predict_from_stem   the rest of the CNN through PyTorch-ROCm (FP32)
     rp_commit_eval      mask / renormalise / expand / backup on device
 
 The groups' waves are launched alternately on their streams, so the latency-bound tree walk of one group runs while the
@@ -32,20 +33,39 @@ class _Group:
                                node_cap=owner.node_cap, edge_cap=owner.edge_cap, device=owner.device.index or 0,
                                stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group)
         self.eng.set_step_cap(owner.step_cap)
-        self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
+        self.use_stem = owner.use_stem
+        if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
+            self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device)
+            self.planes = None
+        else:
+            self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
         self.graph = None
         self.pi = self.v = None
 
+    def refresh_weights(self, nnet):
+        if self.use_stem:
+            w, b = nnet.stem_params()
+            self._stem_w, self._stem_b = w, b  # keep alive until the table kernel ran
+            self.eng.stem_set_weights(w.data_ptr(), b.data_ptr())
+
+    def forward(self, nnet):
+        if self.use_stem:
+            return nnet.predict_from_stem(self.stem)
+        return nnet.predict_batch(self.planes)
+
     def wave_eager(self, nnet):
         self.eng.search_step(sync=False)
-        self.eng.leaf_planes(self.planes.data_ptr(), self.G)
-        self.pi, self.v = nnet.predict_batch(self.planes)
+        if self.use_stem:
+            self.eng.leaf_stem(self.stem.data_ptr(), self.G)
+        else:
+            self.eng.leaf_planes(self.planes.data_ptr(), self.G)
+        self.pi, self.v = self.forward(nnet)
         self.eng.commit_eval(self.pi.data_ptr(), self.v.data_ptr())
 
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -57,6 +77,7 @@ class BatchedSelfPlay:
         self.move_rule, self.node_cap, self.edge_cap, self.step_cap = move_rule, node_cap, edge_cap, int(step_cap)
         self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
         self.use_graph = use_graph
+        self.use_stem = bool(use_stem)
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
         self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0
@@ -87,8 +108,9 @@ class BatchedSelfPlay:
                 continue
             torch.cuda.synchronize(self.device)
             with torch.cuda.stream(g.stream):
+                g.refresh_weights(self.nnet)
                 for _ in range(3):
-                    self.nnet.predict_batch(g.planes)
+                    g.forward(self.nnet)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=g.stream):
@@ -132,8 +154,11 @@ class BatchedSelfPlay:
         self.first_id = int(first_id)
         self.n_instances = item_wh.shape[0]
         k = len(self.groups)
+        torch.cuda.synchronize(self.device)  # the evaluator's weights may just have been trained on another stream
         for g in self.groups:
             wh_g = np.ascontiguousarray(item_wh[g.index::k]); area_g = np.ascontiguousarray(total_area[g.index::k])
+            with torch.cuda.stream(g.stream):
+                g.refresh_weights(self.nnet)  # stem tables follow in-place weight updates
             g.eng.set_rank_buffer(buf)
             g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), 0))
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))

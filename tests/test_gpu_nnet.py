@@ -139,3 +139,41 @@ def test_coach_iteration_runs_and_trains():
     assert (pi[-1] > 0).sum() == 1  # iteration 2 > iterStepThreshold: greedy one-hot targets (MCTS_bpp.py:43-49)
     assert any(not torch.equal(a, b.detach()) for a, b in zip(before, net.nnet.parameters()))
     assert os.path.exists("/tmp/rp_coach_test/temp.pth.tar") and os.path.exists("/tmp/rp_coach_test/rewards_list_8_items.pkl")
+
+
+@pytest.mark.parametrize("name", ["c2_seed0", "c3_seed0", "w15_trained"])
+def test_engine_stem_matches_conv_and_pool(name):
+    """rp_leaf_stem (first conv + max-pool from the packed state via tabulated tap sums) against the dense PyTorch ops on the
+    planes of the same leaves, and the whole evaluator through the stem against the full forward."""
+    import torch
+    import torch.nn.functional as F
+    from resource_packing_self_play_amd import _lib
+    from test_gpu_mcts import gen_items
+    d = np.load(os.path.join(GOLDEN, "nnet_%s.npz" % name))
+    game, net, args = gpu_wrapper(d)
+    W, H, N = game.bin_width, game.bin_height, game.num_items
+    games = 64
+    rng = np.random.default_rng(N)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+    eng = _lib.Engine(W, H, N, games, 12, move_rule=_lib.MOVE_SAMPLE, seed=3, stream=torch.cuda.current_stream().cuda_stream)
+    w, b = net.stem_params()
+    eng.stem_set_weights(w.data_ptr(), b.data_ptr())
+    eng.begin_episodes(wh, np.full(games, W * H, np.int32))
+    planes = torch.zeros((games, N + 1, H, W), device="cuda"); stem = torch.zeros((games, 16, (H + 1) // 2, (W + 1) // 2), device="cuda")
+    conv = net.nnet.conv_seqs[0].conv
+    worst_stem = worst_pi = 0.0
+    for step in range(60):
+        n = eng.search_step()
+        if n == 0:
+            break
+        eng.leaf_planes(planes.data_ptr(), games); eng.leaf_stem(stem.data_ptr(), games)
+        with torch.no_grad():
+            want = F.max_pool2d(conv(planes[:n]), kernel_size=3, stride=2, padding=1)
+        worst_stem = max(worst_stem, float((stem[:n] - want).abs().max()))
+        pi_a, v_a = net.predict_batch(planes[:n]); pi_b, v_b = net.predict_from_stem(stem[:n])
+        worst_pi = max(worst_pi, float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max()))
+        eng.commit_eval(pi_a.data_ptr(), v_a.data_ptr()) if n == games else eng.commit_eval_host(pi_a.cpu().numpy(), v_a.cpu().numpy())
+    print("stem max |delta| %.3e, pi/v max |delta| %.3e" % (worst_stem, worst_pi))
+    assert step > 20
+    assert worst_stem <= 2e-5 and worst_pi <= (1e-4 if name == "w15_trained" else TOL)
+    eng.close()
