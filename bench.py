@@ -143,10 +143,10 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--games", type=int, default=4096, help="concurrent game slots per GPU")
-    ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default 2 x games)")
+    ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
+    ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
-    ap.add_argument("--edge-factor", type=int, default=72, help="edge arena = node arena x this")
+    ap.add_argument("--edge-factor", type=int, default=128, help="legal-move arena = node arena x this (6 B per entry)")
     ap.add_argument("--groups", type=int, default=2, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
     ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
@@ -184,7 +184,7 @@ def main():
     args = Args(numMCTSSims=sims, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=64)
     torch.manual_seed(0)
     nnet = NNetWrapper(game, args)
-    pool = a.pool or 2 * a.games
+    pool = a.pool or a.games
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem)
