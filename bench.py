@@ -259,13 +259,15 @@ def main():
     if W > 32:
         K = 8 * H + (N + 31) // 32 * 4
     A = W * N
-    # algorithmic bytes of the tree walk with THIS layout: per selected node 16 B header + 20 B per
-    # valid edge (P f64, Q f64, N u32) + 6 B (child, action); per path edge backed up 32 B (Q, N, Ns read + write);
-    # per expansion: key write K + one 512 B probe window + key compare K + header 16 + edge init 26 B per valid move +
-    # prior write 8 B per valid move + evaluator output 4A + 4.
-    sel_bytes = 22.0 * tot["path_edges"] + 20.0 * tot["sum_valid_select"]
+    # algorithmic bytes of the tree walk with THIS layout.  Per selected node: 32 B header, 4 B prior per
+    # unvisited legal move, 22 B per visited entry (idx, N, Q, P), 6 B (child, action); 26 B per visited entry created;
+    # per backed-up edge 32 B (Q, N, Ns read + write); per expansion: key write + compare 2K, one 512 B probe window,
+    # 32 B header write, 2 B action write per legal move (k_search) and, in k_commit, the 64 B header read-modify-write,
+    # the evaluator's 4A + 4 B output, 2 B action read + 4 B prior write per legal move.
+    sel_bytes = 38.0 * tot["path_edges"] + 4.0 * (tot["sum_valid_select"] - tot["sum_visited_select"]) + 22.0 * tot["sum_visited_select"] \
+        + 26.0 * tot["visited_new"]
     bak_bytes = 32.0 * tot["path_edges"]
-    exp_bytes = tot["expansions"] * (2 * K + 512 + 16 + 4 * A + 4) + 34.0 * tot["sum_valid_leaf"]
+    exp_bytes = tot["expansions"] * (2 * K + 512 + 32 + 64 + 4 * A + 4) + 8.0 * tot["sum_valid_leaf"]
     tree_bytes = sel_bytes + bak_bytes + exp_bytes
     per_wave = phase_ms / max(phase_n, 1)  # ms per wave: search, planes, evaluator, commit
     tree_ms = per_wave[0] + per_wave[3]

@@ -191,8 +191,9 @@ int rp_pop_finished(rp_ctx *ctx, int64_t max_n, uint64_t *episode_id_out, int32_
 /* Engine counters summed over slots since create/reset: [0] simulations, [1] expansions (leaf evaluations),
  * [2] terminal returns, [3] path edges walked, [4] sum of n_valid at selected nodes, [5] sum of n_valid at
  * expanded leaves, [6] transposition links, [7] nodes created, [8] moves played, [9] episodes finished,
- * [10] hash probes (64-slot windows), [11] key bytes compared. */
-int rp_counters(rp_ctx *ctx, int64_t *out12, int32_t reset);
+ * [10] hash probes (64-slot windows), [11] key bytes compared, [12] sum of visited edges at selected nodes,
+ * [13] visited-edge entries created, [14..15] reserved. */
+int rp_counters(rp_ctx *ctx, int64_t *out16, int32_t reset);
 
 /* ---- replay buffer (CoachBPP.executeEpisode's trainExamples, CoachBPP.py:80,99) -------- */
 /* Number of examples recorded so far. */

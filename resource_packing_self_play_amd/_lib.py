@@ -18,7 +18,8 @@ PHASE_IDLE, PHASE_RUNNING, PHASE_WAIT_EVAL, PHASE_MOVE_READY, PHASE_EPISODE_DONE
 KIND_WEAK, KIND_F32, KIND_F64 = 0, 1, 2
 ERR_ARG, ERR_DEVICE, ERR_CAPACITY, ERR_ASSERT, ERR_STATE = -1, -2, -3, -4, -5
 COUNTER_NAMES = ("simulations", "expansions", "terminal_returns", "path_edges", "sum_valid_select", "sum_valid_leaf",
-                 "transposition_links", "nodes", "moves", "episodes", "hash_probes", "key_bytes")
+                 "transposition_links", "nodes", "moves", "episodes", "hash_probes", "key_bytes", "sum_visited_select", "visited_new",
+                 "reserved0", "reserved1")
 
 
 class RpConfig(C.Structure):
@@ -300,7 +301,7 @@ class Engine:
         return ids[:k], oc[:k], sc[:k], mv[:k]
 
     def counters(self, reset=False):
-        out = np.zeros(12, np.int64)
+        out = np.zeros(16, np.int64)
         self._ck(self.L.rp_counters(self.h, _ptr(out), 1 if reset else 0))
         return dict(zip(COUNTER_NAMES, out.tolist()))
 

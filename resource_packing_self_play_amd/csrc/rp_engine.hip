@@ -45,7 +45,7 @@ typedef unsigned char u8;
 #define MAX_MASK_WORDS 256 /* A <= 8192 */
 
 enum { CNT_SIMS = 0, CNT_EXPAND, CNT_TERMINAL, CNT_PATH, CNT_NVALID_SEL, CNT_NVALID_LEAF, CNT_TRANSPOSE, CNT_NODES,
-       CNT_MOVES, CNT_EPISODES, CNT_PROBES, CNT_KEYBYTES, CNT_N };
+       CNT_MOVES, CNT_EPISODES, CNT_PROBES, CNT_KEYBYTES, CNT_VIS_SEL, CNT_VIS_NEW, CNT_RES0, CNT_RES1, CNT_N };
 enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7, ERR_VIS_CAP = 8 };
 
 struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
@@ -792,12 +792,14 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
             }
             if (!(hd.flags & HF_EXPANDED)) { need_eval = true; break; }  // :85 leaf
             u32 ksel;
+            const u32 vis_before = hd.vis_n;
             u32 e = t.select_edge(node, hd, vmask, ksel);
+            c[CNT_VIS_NEW] += hd.vis_n - vis_before;
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
             if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
             else if (lane == depth - 64) { pe1 = e; pn1 = node; }
             depth++;
-            c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid;
+            c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid; c[CNT_VIS_SEL] += vis_before;
             wave_sync();
             u32 child = t.vChild[e];
             if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
@@ -1889,9 +1891,9 @@ extern "C" int rp_examples_clear(rp_ctx *ctx) {
     return RP_OK;
 }
 
-extern "C" int rp_counters(rp_ctx *ctx, int64_t *out12, int32_t reset) {
-    if (!ctx || !out12) return fail(ctx, RP_ERR_ARG, "rp_counters: bad argument");
-    HIPCHK(ctx, hipMemcpyAsync(out12, ctx->d.counters, CNT_N * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+extern "C" int rp_counters(rp_ctx *ctx, int64_t *out16, int32_t reset) {
+    if (!ctx || !out16) return fail(ctx, RP_ERR_ARG, "rp_counters: bad argument");
+    HIPCHK(ctx, hipMemcpyAsync(out16, ctx->d.counters, CNT_N * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d.counters, 0, CNT_N * sizeof(u64), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RP_OK;
