@@ -854,32 +854,39 @@ __device__ __forceinline__ double prior_term(const float *pi, const u32 *vmask, 
     double x = (double)pi[a] * valid;
     return mode ? x + valid : x;
 }
-__device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmask, double *sleaf, int mode) {
+#define TERM_CHUNK 1024  /* 8 leaves x <= 128 elements */
+__device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmask, double *sleaf, double *sterm, int mode) {
     const int lane = lane_id(), j = lane & 7;
     for (int lb = 0; lb < p.n_leaves; lb += 8) {
+        // the 8 leaves of this pass cover one contiguous element range: build its float64 terms with coalesced loads ...
+        const int lend = (lb + 8 < p.n_leaves ? lb + 8 : p.n_leaves) - 1;
+        const int glo = p.leaf_lo[lb], ghi = p.leaf_lo[lend] + p.leaf_n[lend];
+        for (int a = glo + lane; a < ghi; a += 64) sterm[a - glo] = prior_term(pi, vmask, a, mode);
+        wave_sync();
+        // ... then every (leaf, accumulator) pair runs its sequential chain out of LDS
         int l = lb + (lane >> 3);
         bool act = l < p.n_leaves;
-        int lo = act ? p.leaf_lo[l] : 0, n = act ? p.leaf_n[l] : 0;
+        int lo = act ? p.leaf_lo[l] - glo : 0, n = act ? p.leaf_n[l] : 0;
         double res = 0.0;
         if (n >= 8) {
             int n8 = n - (n & 7);
-            double r = prior_term(pi, vmask, lo + j, mode);
-            for (int i = 8 + j; i < n8; i += 8) r = r + prior_term(pi, vmask, lo + i, mode);
+            double r = sterm[lo + j];
+            for (int i = 8 + j; i < n8; i += 8) r = r + sterm[lo + i];
             double s1 = r + __shfl_down(r, 1);     // r0+r1, r2+r3, ...
             double s2 = s1 + __shfl_down(s1, 2);   // (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
             double s3 = s2 + __shfl_down(s2, 4);
             res = s3;
             if (j == 0)
-                for (int i = n8; i < n; ++i) res = res + prior_term(pi, vmask, lo + i, mode);
+                for (int i = n8; i < n; ++i) res = res + sterm[lo + i];
         } else {
             if (act && j == 0) {
                 res = -0.0;
-                for (int i = 0; i < n; ++i) res = res + prior_term(pi, vmask, lo + i, mode);
+                for (int i = 0; i < n; ++i) res = res + sterm[lo + i];
             }
         }
         if (act && j == 0) sleaf[l] = res;
+        wave_sync();
     }
-    wave_sync();
     if (lane == 0)
         for (int k = 0; k < p.n_leaves - 1; ++k) sleaf[p.sched_dst[k]] = sleaf[p.sched_dst[k]] + sleaf[p.sched_src[k]];
     wave_sync();
@@ -891,16 +898,16 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
 // Normaliser of one node's masked prior from the evaluator's pi (MCTS_bpp.py:88-100): np.sum(pi * valids) if that is
 // positive, else the sum of the uniform fallback pi * valids + valids.  The legal moves' float32 pi go to `pi_out`.
 __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, float *pi_out, u32 n_valid, u32 *vmask, double *sleaf,
-                               bool *fallback) {
+                               double *sterm, bool *fallback) {
     const int lane = lane_id();
     const int words = (p.A + 31) >> 5;
     for (int w = lane; w < words; w += 64) vmask[w] = 0u;
     wave_sync();
     for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); pi_out[k] = pi[a]; }
     wave_sync();
-    double s = numpy_masked_sum(p, pi, vmask, sleaf, 0);
-    *fallback = !(s > 0);                                      // :91
-    if (*fallback) s = numpy_masked_sum(p, pi, vmask, sleaf, 1);  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
+    double s = numpy_masked_sum(p, pi, vmask, sleaf, sterm, 0);
+    *fallback = !(s > 0);                                             // :91
+    if (*fallback) s = numpy_masked_sum(p, pi, vmask, sleaf, sterm, 1);  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
     return s;
 }
 
@@ -909,6 +916,7 @@ template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const float *pi, const float *vv) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
+    __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id(), wv = threadIdx.x >> 6;
     if (b >= *p.eval_count) return;
     const int g = p.eval_slot[b];
@@ -916,7 +924,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     const u32 node = p.leaf_node[g];
     NodeHdr hd = t.hdr[node];
     bool fb;
-    double norm = masked_prior(p, pi + (size_t)b * p.A, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], &fb);
+    double norm = masked_prior(p, pi + (size_t)b * p.A, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
         hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
         t.hdr[node] = hd;
@@ -925,11 +933,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     const int depth = p.path_len[g];
     const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
     for (int d = lane; d < depth; d += 64) t.backup_entry(pn[d], pe[d], v, RP_KIND_F32);
-    u64 c[CNT_N];
-    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
-    c[CNT_SIMS] = 1; c[CNT_EXPAND] = 1; c[CNT_NVALID_LEAF] = hd.n_valid;
-    if (lane == 0) { p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32; }
-    add_counters(p, c);
+    if (lane == 0) {
+        p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32;
+        atomicAdd(p.counters + CNT_SIMS, 1ull); atomicAdd(p.counters + CNT_EXPAND, 1ull);
+        atomicAdd(p.counters + CNT_NVALID_LEAF, (u64)hd.n_valid);
+    }
 }
 
 // Evaluator input of the waiting leaves: getBinItem's (N+1, H, W) planes as float32 (BinPackingGame.py:118-120,
@@ -1013,7 +1021,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
     Tree<row_t> t(p, g);
     row_t myrow; u64 rem0, rem1;
     t.load_key(p.leaf_node[g], myrow, rem0, rem1);
-    const u8 *wh = t.wh;
+    // item sizes live in lanes (item i in lane i & 63), broadcast with readlane inside the uniform item loop: no memory traffic
+    int wh_lo = 0, wh_hi = 0;
+    if (lane < p.N) wh_lo = t.wh[2 * lane] | (t.wh[2 * lane + 1] << 8);
+    if (lane + 64 < p.N) wh_hi = t.wh[2 * (lane + 64)] | (t.wh[2 * (lane + 64) + 1] << 8);
     const int P = p.Hp * p.Wp;
     float *ob = out + (size_t)b * STEM_C * P;
     float bias[STEM_C];
@@ -1033,40 +1044,54 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
         float best[STEM_C];
 #pragma unroll
         for (int o = 0; o < STEM_C; ++o) best[o] = -INFINITY;
-#pragma unroll
-        for (int wr = 0; wr < 3; ++wr) {
+        for (int wr = 0; wr < 3; ++wr) {  // one row of the pooling window at a time: three convolution outputs per lane
             const int r = 2 * pr - 1 + wr;
+            const bool rowok = live && r >= 0 && r < p.H;
+            float acc[3][STEM_C];
 #pragma unroll
-            for (int wx = 0; wx < 3; ++wx) {
+            for (int wx = 0; wx < 3; ++wx)
+#pragma unroll
+                for (int o = 0; o < STEM_C; ++o) acc[wx][o] = bias[o];
+            const row_t r0 = wr == 0 ? rw[0] : (wr == 1 ? rw[1] : rw[2]), r1 = wr == 0 ? rw[1] : (wr == 1 ? rw[2] : rw[3]),
+                        r2 = wr == 0 ? rw[2] : (wr == 1 ? rw[3] : rw[4]);
+#pragma unroll
+            for (int wx = 0; wx < 3; ++wx) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
                 const int x = 2 * px - 1 + wx;
-                const bool inside = live && r >= 0 && r < p.H && x >= 0 && x < p.W;
-                if (!inside) continue;
-                float acc[STEM_C];
-#pragma unroll
-                for (int o = 0; o < STEM_C; ++o) acc[o] = bias[o];
-                // grid plane: 3x3 bit pattern around (r, x), bit dr*3+dx = cell (r+dr-1, x+dx-1)
-                u32 pat = 0;
-#pragma unroll
-                for (int dr = 0; dr < 3; ++dr) {
-                    row_t row = rw[wr + dr];
-                    u32 bits = x ? (u32)((row >> (x - 1)) & 7) : (u32)((row << 1) & 7);
-                    pat |= bits << (3 * dr);
-                }
+                if (!(rowok && x >= 0 && x < p.W)) continue;
+                u32 b0 = x ? (u32)((r0 >> (x - 1)) & 7) : (u32)((r0 << 1) & 7);
+                u32 b1 = x ? (u32)((r1 >> (x - 1)) & 7) : (u32)((r1 << 1) & 7);
+                u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
+                u32 pat = b0 | (b1 << 3) | (b2 << 6);
                 if (pat) {
                     const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w; }
+                    for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
                 }
-                for (int i = 0; i < p.N; ++i) {
-                    if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
-                    int rc = stem_class(r, wh[2 * i + 1]), cc = stem_class(x, wh[2 * i]);
-                    if (rc < 0 || cc < 0) continue;
-                    const float4 *tt = (const float4 *)(p.stemT + ((size_t)(i * 5 + rc) * 5 + cc) * STEM_C);
+            }
+            for (int i = 0; i < p.N; ++i) {
+                if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
+                const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
+                const int iw = whi & 255, ih = whi >> 8;
+                const int rc = rowok ? stem_class(r, ih) : -1;
+                if (__ballot(rc >= 0) == 0ull) continue;  // no lane's row touches this item
+                if (rc < 0) continue;
+                const float *trow = p.stemT + (size_t)(i * 5 + rc) * 5 * STEM_C;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w; }
+                for (int wx = 0; wx < 3; ++wx) {
+                    const int x = 2 * px - 1 + wx;
+                    const int cc = (x >= 0 && x < p.W) ? stem_class(x, iw) : -1;
+                    if (cc < 0) continue;
+                    const float4 *tt = (const float4 *)(trow + cc * STEM_C);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
                 }
+            }
 #pragma unroll
-                for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[o]);
+            for (int wx = 0; wx < 3; ++wx) {
+                const int x = 2 * px - 1 + wx;
+                if (!(rowok && x >= 0 && x < p.W)) continue;
+#pragma unroll
+                for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[wx][o]);
             }
         }
         if (live) {
@@ -1287,6 +1312,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
                                                                           float *pi_scratch) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
+    __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
     const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -1304,7 +1330,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
     }
     wave_sync();
     bool fb;
-    double norm = masked_prior(p, pi + b * p.A, act, pc, (u32)nv, s_mask[wv], s_leaf[wv], &fb);
+    double norm = masked_prior(p, pi + b * p.A, act, pc, (u32)nv, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
     wave_sync();
     for (int k = lane; k < nv; k += 64) o[act[k]] = Tree<u32>::prior_of(pc[k], norm, fb);
 }
