@@ -59,7 +59,10 @@ _SIGS = {
     "rp_search_step": (C.c_int, [_vp, _vp]),
     "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
     "rp_stem_set_weights": (C.c_int, [_vp, _vp, _vp]),
-    "rp_leaf_stem": (C.c_int, [_vp, _vp, _i64]),
+    "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
+    "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "rp_commit_eval": (C.c_int, [_vp, _vp, _vp]),
     "rp_commit_eval_host": (C.c_int, [_vp, _vp, _vp, _i32]),
@@ -135,6 +138,7 @@ class Engine:
                  node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0):
         self.L = load()
         self.W, self.H, self.N, self.A, self.G, self.sims = int(W), int(H), int(N), int(W) * int(N), int(games), int(sims)
+        self.move_rule = int(move_rule)
         cfg = RpConfig(ABI_VERSION, W, H, N, games, sims, float(cpuct), float(alpha), node_cap, edge_cap, move_rule,
                        auto_restart, seed, tie_salt, device, vis_cap, stream or None, max_examples)
         h = _vp()
@@ -214,6 +218,7 @@ class Engine:
 
     def set_move_rule(self, move_rule, onehot_examples=False):
         self._ck(self.L.rp_set_move_rule(self.h, int(move_rule), 1 if onehot_examples else 0))
+        self.move_rule = int(move_rule)
 
     def set_sims(self, sims):
         self._ck(self.L.rp_set_sims(self.h, int(sims)))
@@ -240,8 +245,25 @@ class Engine:
     def stem_set_weights(self, conv_w_dev_ptr, bias_dev_ptr):
         self._ck(self.L.rp_stem_set_weights(self.h, C.c_void_p(conv_w_dev_ptr), C.c_void_p(bias_dev_ptr)))
 
-    def leaf_stem(self, dev_ptr, capacity_rows):
-        self._ck(self.L.rp_leaf_stem(self.h, C.c_void_p(dev_ptr), capacity_rows))
+    def leaf_stem(self, dev_ptr, capacity_rows, relu_dev_ptr=None):
+        self._ck(self.L.rp_leaf_stem(self.h, C.c_void_p(dev_ptr), C.c_void_p(relu_dev_ptr) if relu_dev_ptr else None, capacity_rows))
+
+    # fused element-wise evaluator pieces on torch tensors (contiguous float32 NCHW on this context's device)
+    def nn_bias_relu(self, x, bias):
+        B, Cc = x.shape[0], x.shape[1]
+        self._ck(self.L.rp_nn_bias_relu(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), B, Cc, x[0, 0].numel()))
+        return x
+
+    def nn_bias_residual(self, x, bias, res, out, out_relu=None):
+        B, Cc = x.shape[0], x.shape[1]
+        self._ck(self.L.rp_nn_bias_residual(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()),
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None,
+                                            B, Cc, x[0, 0].numel()))
+
+    def nn_bias_pool(self, x, bias, out, out_relu=None):
+        B, Cc, H, W = x.shape
+        self._ck(self.L.rp_nn_bias_pool(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, Cc, H, W))
 
     def leaf_states(self, max_rows=None):
         max_rows = self.G if max_rows is None else max_rows
@@ -267,7 +289,10 @@ class Engine:
         while steps < max_steps:
             n = self.search_step()
             if n == 0:
-                return steps
+                busy = (PHASE_RUNNING,) if self.move_rule == MOVE_EXTERNAL else (PHASE_RUNNING, PHASE_MOVE_READY)
+                if not np.isin(self.status()[0], busy).any():
+                    return steps
+                continue
             rows, rem, _ = self.leaf_states(n)
             pi, v = evaluate(rows, rem)
             self.commit_eval_host(pi, v)

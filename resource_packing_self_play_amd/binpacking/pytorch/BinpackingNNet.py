@@ -83,6 +83,30 @@ class BinPackingNNet(nn.Module):
     def forward(self, x):
         return self.heads(self.trunk(x))
 
+    def forward_from_stem_fused(self, y, y_relu, ops):
+        """Same network as forward_from_stem with the element-wise work fused: convolutions run without bias through
+        PyTorch-ROCm, and `ops` (an engine: rp_nn_bias_relu / rp_nn_bias_residual / rp_nn_bias_pool) applies bias + ReLU,
+        bias + skip (+ the next block's ReLU) and bias + max-pool in one pass each -- 4 kernels per residual block
+        instead of 7, the same float32 operations in the same order.  y_relu = relu(y).  Returns (softmax, tanh)."""
+        x, xr = y, y_relu
+        for si, stage in enumerate(self.conv_seqs):
+            if si > 0:
+                c = F.conv2d(x, stage.conv.weight, None, padding=1)
+                b, ch, h, w = c.shape
+                x = c.new_empty((b, ch, (h + 1) // 2, (w + 1) // 2))
+                xr = torch.empty_like(x)
+                ops.nn_bias_pool(c, stage.conv.bias, x, xr)
+            for blk in (stage.res_block0, stage.res_block1):
+                c0 = F.conv2d(xr, blk.conv0.weight, None, padding=1)
+                ops.nn_bias_relu(c0, blk.conv0.bias)
+                c1 = F.conv2d(c0, blk.conv1.weight, None, padding=1)
+                out, out_r = torch.empty_like(c1), torch.empty_like(c1)
+                ops.nn_bias_residual(c1, blk.conv1.bias, x, out, out_r)
+                x, xr = out, out_r
+        z = F.linear(torch.flatten(xr, start_dim=1), self.hidden_fc.weight, None)
+        ops.nn_bias_relu(z.view(z.shape[0], z.shape[1], 1, 1), self.hidden_fc.bias)
+        return torch.softmax(self.logits_fc(z), dim=1), torch.tanh(self.value_fc(z))
+
     def forward_from_stem(self, y):
         """y = max_pool2d(conv_seqs[0].conv(x), 3, 2, 1), e.g. from the engine's rp_leaf_stem: the rest of the network."""
         st0 = self.conv_seqs[0]

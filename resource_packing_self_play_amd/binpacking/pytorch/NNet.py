@@ -52,10 +52,15 @@ class NNetWrapper(NeuralNet):
         conv = self.nnet.conv_seqs[0].conv
         return conv.weight.detach().contiguous(), conv.bias.detach().contiguous()
 
-    def predict_from_stem(self, stem):
-        """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch."""
+    def predict_from_stem(self, stem, stem_relu=None, ops=None):
+        """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch.
+        With `stem_relu` (= relu(stem), also written by rp_leaf_stem) and `ops` (the engine) the element-wise work runs
+        through the engine's fused kernels."""
         self.nnet.eval()
         with torch.no_grad():
+            if ops is not None and stem_relu is not None:
+                pi, v = self.nnet.forward_from_stem_fused(stem, stem_relu, ops)
+                return pi.contiguous(), v.reshape(-1).contiguous()
             log_pi, v = self.nnet.forward_from_stem(stem)
             return torch.exp(log_pi).contiguous(), v.reshape(-1).contiguous()
 

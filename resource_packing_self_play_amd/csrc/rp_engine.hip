@@ -99,9 +99,10 @@ struct DP {  // device view of a context, passed by value to every kernel
     double *vP;     //                Ps[s][a] = float64(pi) / norm
     u32 *vChild;    //                child node id (NONE32 until first traversed)
     u64 *table;     // [G][table_cap]  (tag << 32) | (node id + 1), 0 = empty
-    // NumPy pairwise-sum plan over A elements
+    // NumPy pairwise-sum plan over A elements, carried in the kernel arguments (scalar loads)
     int n_leaves;
-    const int *leaf_lo, *leaf_n, *sched_dst, *sched_src;
+    u16 leaf_lo[MAX_LEAVES];
+    u8 leaf_n[MAX_LEAVES], sched_dst[MAX_LEAVES], sched_src[MAX_LEAVES];
     // global
     double *g_bl;
     int *g_has_buf;
@@ -567,18 +568,18 @@ template <typename row_t> struct Tree {
     }
 };
 
-__device__ void add_counters(const DP &p, const u64 *c) {
+template <typename T> __device__ void add_counters(const DP &p, const T *c) {
     if (lane_id() == 0)
         for (int k = 0; k < CNT_N; ++k)
-            if (c[k]) atomicAdd(p.counters + k, c[k]);
+            if (c[k]) atomicAdd(p.counters + k, (u64)c[k]);
 }
 
 __device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(mix64(seed) ^ episode) ^ move); }
 
 // CoachBPP.executeEpisode's move (CoachBPP.py:86-99) for one slot whose search budget is spent.
 // action < 0: pick by p.move_rule.  Leaves phase RUNNING, EPISODE_DONE or FAILED.
-template <typename row_t>
-__device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, u64 *c) {
+template <typename row_t, typename CT>
+__device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, CT *c) {
     NodeHdr hd = t.hdr[root];
     const int lane = lane_id();
     u32 chosen = NONE32;  // visited entry of the move that is played
@@ -705,8 +706,8 @@ __device__ void play_move(const DP &p, Tree<row_t> &t, int g, u32 &root, int act
 
 // A slot whose episode ended takes the next instance of the pool (CoachBPP.py:123-134: the next self-play
 // episode, a new MCTS with an empty tree).  Leaves the slot RUNNING at the new root, or IDLE when the pool is used up.
-template <typename row_t>
-__device__ void restart_slot(const DP &p, Tree<row_t> &t, int g, u32 &root, u64 *c) {
+template <typename row_t, typename CT>
+__device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, CT *c) {
     const int lane = lane_id();
     unsigned long long idx = 0;
     if (lane == 0) idx = atomicAdd(p.next_instance, 1ull);
@@ -748,9 +749,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (g >= p.G) return;
     int phase = p.phase[g];
-    if (phase != RP_PHASE_RUNNING && !(phase == RP_PHASE_MOVE_READY && p.move_rule != RP_MOVE_EXTERNAL)) return;
+    if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
     Tree<row_t> t(p, g);
-    u64 c[CNT_N];
+    u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
@@ -759,24 +760,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
         // A slot near the end of its game runs many evaluator-free simulations (terminal hits); the cap bounds the
         // launch's tail so one such slot cannot stall the whole wave.  Pure scheduling: results do not depend on it.
         if (p.step_cap > 0 && launched >= p.step_cap) break;
-        if (phase == RP_PHASE_MOVE_READY) {
-            if (p.move_rule == RP_MOVE_EXTERNAL) break;
-            play_move<row_t>(p, t, g, root, -1, c);
-            wave_sync();
-            phase = p.phase[g];
-            if (phase == RP_PHASE_EPISODE_DONE && p.auto_restart) {
-                restart_slot<row_t>(p, t, g, root, c);
-                wave_sync();
-                phase = p.phase[g];
-            }
-            sims_done = 0;
-            if (phase != RP_PHASE_RUNNING) break;
-        }
-        if (sims_done >= p.sims) {  // for i in range(numMCTSSims) done (MCTS_bpp.py:37-38)
+        if (sims_done >= p.sims) {  // for i in range(numMCTSSims) done (MCTS_bpp.py:37-38): the move is k_moves' job
             phase = RP_PHASE_MOVE_READY;
-            if (lane == 0) { p.phase[g] = phase; p.sims_done[g] = sims_done; }
-            wave_sync();
-            continue;
+            break;
         }
         // ---- one simulation ----
         u32 node = root, pe0 = NONE32, pn0 = NONE32, pe1 = NONE32, pn1 = NONE32;
@@ -840,10 +826,30 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
     }
     t.store_sizes();
     c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
-    if (lane == 0) {
-        if (phase != RP_PHASE_EPISODE_DONE && phase != RP_PHASE_IDLE) p.phase[g] = phase;
-        if (phase == RP_PHASE_WAIT_EVAL || phase == RP_PHASE_FAILED || phase == RP_PHASE_RUNNING) p.sims_done[g] = sims_done;
+    if (lane == 0) { p.phase[g] = phase; p.sims_done[g] = sims_done; }
+    add_counters(p, c);
+}
+
+// CoachBPP.executeEpisode's move for every slot whose search budget is spent (RP_MOVE_ARGMAX_FIRST / RP_MOVE_SAMPLE), and the
+// next instance of the pool for a slot whose episode ended.  Launched right before k_search; a separate kernel so that the
+// simulation loop does not carry this code's registers.
+template <typename row_t>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
+    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (g >= p.G) return;
+    if (p.phase[g] != RP_PHASE_MOVE_READY) return;
+    Tree<row_t> t(p, g);
+    u32 c[CNT_N];
+    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
+    u32 root = p.root[g];
+    play_move_impl<row_t>(p, t, g, root, -1, c);
+    wave_sync();
+    if (p.phase[g] == RP_PHASE_EPISODE_DONE && p.auto_restart) {
+        restart_slot_impl<row_t>(p, t, g, root, c);
+        wave_sync();
     }
+    t.store_sizes();
+    c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
     add_counters(p, c);
 }
 
@@ -1014,7 +1020,7 @@ __global__ void k_stem_tables(int N, const float *w /*[16][N+1][3][3]*/, const f
 }
 
 template <typename row_t>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, long long capacity_rows) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows) {
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (b >= *p.eval_count || b >= capacity_rows) return;
     const int g = p.eval_slot[b];
@@ -1097,6 +1103,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
         if (live) {
 #pragma unroll
             for (int o = 0; o < STEM_C; ++o) ob[(size_t)o * P + pp] = best[o];
+            if (out_relu) {
+                float *orl = out_relu + (size_t)b * STEM_C * P;
+#pragma unroll
+                for (int o = 0; o < STEM_C; ++o) orl[(size_t)o * P + pp] = best[o] > 0.f ? best[o] : 0.f;
+            }
         }
     }
 }
@@ -1172,7 +1183,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = p.root[g];
-    play_move<row_t>(p, t, g, root, action[k], c);
+    play_move_impl<row_t>(p, t, g, root, action[k], c);
     t.store_sizes();
     c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
     add_counters(p, c);
@@ -1202,7 +1213,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = NONE32;
-    restart_slot<row_t>(p, t, g, root, c);
+    restart_slot_impl<row_t>(p, t, g, root, c);
     t.store_sizes();
     c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
     add_counters(p, c);
@@ -1333,6 +1344,56 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
     double norm = masked_prior(p, pi + b * p.A, act, pc, (u32)nv, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
     wave_sync();
     for (int k = lane; k < nv; k += 64) o[act[k]] = Tree<u32>::prior_of(pc[k], norm, fb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused element-wise pieces of the evaluator (BinpackingNNet.py:21-27,39-40).  PyTorch-ROCm runs a convolution's bias add,
+// every ReLU, the residual add and the max-pool as separate HBM-bound kernels; these do the same arithmetic in the same
+// order (conv + bias, then ReLU / + skip), one pass over the activations each.  NCHW float32, contiguous.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_nn_bias_relu(float *x, const float *bias, long long n4, int C, int HW) {  // x = relu(x + b[c])
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = ((float4 *)x)[i];
+    long long e = i * 4;
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float t = r[k] + bias[((e + k) / HW) % C]; r[k] = t > 0.f ? t : 0.f; }
+    ((float4 *)x)[i] = make_float4(r[0], r[1], r[2], r[3]);
+}
+__global__ void k_nn_bias_residual(const float *x, const float *bias, const float *res, float *out, float *out_relu, long long n4, int C, int HW) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // out = (x + b[c]) + res ; out_relu = relu(out)
+    if (i >= n4) return;
+    float4 v = ((const float4 *)x)[i], s = ((const float4 *)res)[i];
+    long long e = i * 4;
+    float a[4] = {v.x, v.y, v.z, v.w}, b[4] = {s.x, s.y, s.z, s.w}, o[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = (a[k] + bias[((e + k) / HW) % C]) + b[k]; q[k] = o[k] > 0.f ? o[k] : 0.f; }
+    ((float4 *)out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (out_relu) ((float4 *)out_relu)[i] = make_float4(q[0], q[1], q[2], q[3]);
+}
+// out = max_pool2d(x + b[c], 3, stride 2, pad 1); out_relu = relu(out).  One thread per output element.
+__global__ void k_nn_bias_pool(const float *x, const float *bias, float *out, float *out_relu, long long n_out, int C, int H, int W, int Hp, int Wp) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    int px = (int)(i % Wp), pr = (int)((i / Wp) % Hp);
+    long long plane = i / ((long long)Wp * Hp);
+    const float *xp = x + plane * (long long)H * W;
+    const float b = bias[plane % C];
+    float m = -INFINITY;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+        int r = 2 * pr + dr;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            int c = 2 * px + dx;
+            if (c < 0 || c >= W) continue;
+            m = fmaxf(m, xp[r * W + c] + b);
+        }
+    }
+    out[i] = m;
+    if (out_relu) out_relu[i] = m > 0.f ? m : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1491,9 +1552,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     std::vector<int> llo, ln, sd, ss;
     build_plan(0, d.A, llo, ln, sd, ss);
     if ((int)llo.size() > MAX_LEAVES) rc = fail(nullptr, RP_ERR_ARG, "action space too large");
-    int *plan = nullptr;
     size_t L = llo.size(), S = sd.size();
-    A_(plan, 2 * L + 2 * S + 4);
     if (rc != RP_OK) {
         std::string msg = ctx->err.empty() ? g_create_error : ctx->err;
         for (void *p : ctx->allocs) (void)hipFree(p);
@@ -1502,15 +1561,12 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
                     (double)(G * ((size_t)d.node_cap * (32 + 4 * d.KW) + (size_t)d.edge_cap * 6 + (size_t)d.vis_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
     }
     d.n_leaves = (int)L;
-    d.leaf_lo = plan; d.leaf_n = plan + L; d.sched_dst = plan + 2 * L; d.sched_src = plan + 2 * L + S;
-    std::vector<int> hp;
-    hp.insert(hp.end(), llo.begin(), llo.end()); hp.insert(hp.end(), ln.begin(), ln.end());
-    hp.insert(hp.end(), sd.begin(), sd.end()); hp.insert(hp.end(), ss.begin(), ss.end());
-    if (hipMemcpyAsync(plan, hp.data(), hp.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    for (size_t k = 0; k < L; ++k) { d.leaf_lo[k] = (u16)llo[k]; d.leaf_n[k] = (u8)ln[k]; }
+    for (size_t k = 0; k < S; ++k) { d.sched_dst[k] = (u8)sd[k]; d.sched_src[k] = (u8)ss[k]; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
         for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
-        return fail(nullptr, RP_ERR_DEVICE, "rp_create: plan upload failed");
+        return fail(nullptr, RP_ERR_DEVICE, "rp_create: device initialisation failed");
     }
     *out = ctx;
     return RP_OK;
@@ -1703,6 +1759,7 @@ extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
     if (!ctx) return RP_ERR_ARG;
     const DP &d = ctx->d;
     HIPCHK(ctx, hipMemsetAsync(d.eval_count, 0, sizeof(int), ctx->stream));
+    if (d.move_rule != RP_MOVE_EXTERNAL) DISPATCH(ctx, k_moves, grid_for(d.G), d);
     DISPATCH(ctx, k_search, grid_for(d.G), d);
     if (n_leaves_out) {
         int n = 0;
@@ -1737,13 +1794,47 @@ extern "C" int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const f
     return RP_OK;
 }
 
-extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, int64_t capacity_rows) {
+extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, int64_t capacity_rows) {
     if (!ctx || !out_dev || capacity_rows < 0) return fail(ctx, RP_ERR_ARG, "rp_leaf_stem: bad argument");
     const DP &d = ctx->d;
     if (!d.stemT) return fail(ctx, RP_ERR_STATE, "rp_leaf_stem: call rp_stem_set_weights first");
     long long rows = std::min<long long>(capacity_rows, d.G);
     if (rows == 0) return RP_OK;
-    DISPATCH(ctx, k_leaf_stem, grid_for(rows), d, out_dev, (long long)capacity_rows);
+    DISPATCH(ctx, k_leaf_stem, grid_for(rows), d, out_dev, out_relu_dev, (long long)capacity_rows);
+    return RP_OK;
+}
+
+extern "C" int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW) {
+    if (!ctx || !x_dev || !bias_dev || B < 0 || C < 1 || HW < 1) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_relu: bad argument");
+    long long n = (long long)B * C * HW;
+    if (n % 4) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_relu: element count must be a multiple of 4");
+    if (n == 0) return RP_OK;
+    hipLaunchKernelGGL(k_nn_bias_relu, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, n / 4, (int)C, (int)HW);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
+                                   int64_t B, int32_t C, int32_t HW) {
+    if (!ctx || !x_dev || !bias_dev || !res_dev || !out_dev || B < 0 || C < 1 || HW < 1) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_residual: bad argument");
+    long long n = (long long)B * C * HW;
+    if (n % 4) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_residual: element count must be a multiple of 4");
+    if (n == 0) return RP_OK;
+    hipLaunchKernelGGL(k_nn_bias_residual, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, res_dev, out_dev, out_relu_dev,
+                       n / 4, (int)C, (int)HW);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bias_dev, float *out_dev, float *out_relu_dev, int64_t B, int32_t C, int32_t H,
+                               int32_t W) {
+    if (!ctx || !x_dev || !bias_dev || !out_dev || B < 0 || C < 1 || H < 1 || W < 1) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_pool: bad argument");
+    int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
+    long long n = (long long)B * C * Hp * Wp;
+    if (n == 0) return RP_OK;
+    hipLaunchKernelGGL(k_nn_bias_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C, (int)H,
+                       (int)W, Hp, Wp);
+    HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }
 

@@ -36,6 +36,7 @@ class _Group:
         self.use_stem = owner.use_stem
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
             self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device)
+            self.stem_relu = torch.zeros_like(self.stem) if owner.fuse_elementwise else None
             self.planes = None
         else:
             self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
@@ -50,13 +51,13 @@ class _Group:
 
     def forward(self, nnet):
         if self.use_stem:
-            return nnet.predict_from_stem(self.stem)
+            return nnet.predict_from_stem(self.stem, self.stem_relu, self.eng if self.stem_relu is not None else None)
         return nnet.predict_batch(self.planes)
 
     def wave_eager(self, nnet):
         self.eng.search_step(sync=False)
         if self.use_stem:
-            self.eng.leaf_stem(self.stem.data_ptr(), self.G)
+            self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None)
         else:
             self.eng.leaf_planes(self.planes.data_ptr(), self.G)
         self.pi, self.v = self.forward(nnet)
@@ -65,7 +66,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -78,6 +79,7 @@ class BatchedSelfPlay:
         self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
         self.use_graph = use_graph
         self.use_stem = bool(use_stem)
+        self.fuse_elementwise = bool(fuse_elementwise) and self.use_stem
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
         self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0

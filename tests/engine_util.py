@@ -25,11 +25,16 @@ def host_evaluator(kind_of_slot, A, salt_of_slot):
 
 def run_until_idle(eng, evaluate, max_steps=10 ** 7):
     """search_step / evaluate / commit until no slot waits for the evaluator."""
+    from resource_packing_self_play_amd import _lib
     steps = 0
     while steps < max_steps:
         n = eng.search_step()
         if n == 0:
-            return steps
+            ph = eng.status()[0]
+            busy = (_lib.PHASE_RUNNING,) if eng.move_rule == _lib.MOVE_EXTERNAL else (_lib.PHASE_RUNNING, _lib.PHASE_MOVE_READY)
+            if not np.isin(ph, busy).any():
+                return steps
+            continue  # slots between moves (played at the start of the next step) or stopped by the step cap
         rows, rem, slots = eng.leaf_states(n)
         pi, v = evaluate(rows, rem, slots)
         eng.commit_eval_host(pi, v)

@@ -180,3 +180,37 @@ def test_engine_stem_matches_conv_and_pool(name):
     # 3.8e-5 between batch shapes, tests/test_nnet_cpu.py), so it is held to 5e-4; use_stem=False gives the dense path.
     assert worst_stem <= 2e-5 and worst_pi <= (5e-4 if name == "w15_trained" else TOL)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["c2_seed0", "c3_seed0"])
+def test_fused_elementwise_forward_matches_plain_forward(name):
+    """forward_from_stem_fused (bias+ReLU, bias+skip, bias+pool through the engine's kernels) against forward_from_stem:
+    the same float32 operations in the same order."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    d = np.load(os.path.join(GOLDEN, "nnet_%s.npz" % name))
+    game, net, args = gpu_wrapper(d)
+    W, H, N = game.bin_width, game.bin_height, game.num_items
+    eng = _lib.Engine(W, H, N, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(1)
+    y = torch.randn(257, 16, (H + 1) // 2, (W + 1) // 2, device="cuda")
+    pi_a, v_a = net.predict_from_stem(y)
+    pi_b, v_b = net.predict_from_stem(y, torch.relu(y), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max())
+    print("fused vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-6
+    # the three kernels on their own
+    x = torch.randn(33, 32, 5, 5, device="cuda"); b = torch.randn(32, device="cuda"); r = torch.randn_like(x)
+    want = torch.relu(x + b.view(1, -1, 1, 1))
+    got = eng.nn_bias_relu(x.clone().contiguous()[:32], b)  # 32*32*25 elements (multiple of 4)
+    assert torch.equal(got, want[:32])
+    out, out_r = torch.empty_like(x[:32]), torch.empty_like(x[:32])
+    eng.nn_bias_residual(x[:32].contiguous(), b, r[:32].contiguous(), out, out_r)
+    assert torch.equal(out, (x[:32] + b.view(1, -1, 1, 1)) + r[:32]) and torch.equal(out_r, torch.relu(out))
+    po, po_r = torch.empty(33, 32, 3, 3, device="cuda"), torch.empty(33, 32, 3, 3, device="cuda")
+    eng.nn_bias_pool(x, b, po, po_r)
+    wantp = torch.nn.functional.max_pool2d(x + b.view(1, -1, 1, 1), 3, 2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(po, wantp) and torch.equal(po_r, torch.relu(wantp))
+    eng.close()
