@@ -83,11 +83,47 @@ class BinPackingNNet(nn.Module):
     def forward(self, x):
         return self.heads(self.trunk(x))
 
+    # ---- small-image convolutions as matrices --------------------------------------------------------------------------
+    # On a 3x3 (or smaller) image a padded 3x3 convolution is a dense (C*h*w) x (C*h*w) matrix; MIOpen still pays a full
+    # Winograd launch for it.  The matrices are read off the convolution itself (its response to the identity batch, so every
+    # entry is exactly one weight) and refreshed in place after weight updates, which keeps captured HIP graphs valid.
+    DENSE_MAX_PIXELS = 9
+
+    def _dense_key(self, si, which):
+        return "%d:%s" % (si, which)
+
+    def refresh_dense(self):
+        shapes = stage_shapes(self.in_channels, self.board_h, self.board_w)
+        if not hasattr(self, "_dense"):
+            self._dense = {}
+        with torch.no_grad():
+            for si, stage in enumerate(self.conv_seqs):
+                ch, h, w = shapes[si]
+                if h * w > self.DENSE_MAX_PIXELS:
+                    continue
+                for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
+                    for ci, conv in enumerate((blk.conv0, blk.conv1)):
+                        eye = torch.eye(ch * h * w, device=conv.weight.device, dtype=conv.weight.dtype).view(-1, ch, h, w)
+                        mt = F.conv2d(eye, conv.weight, None, padding=1).flatten(1).contiguous()
+                        key = self._dense_key(si, "b%dc%d" % (bi, ci))
+                        if key in self._dense:
+                            self._dense[key].copy_(mt)
+                        else:
+                            self._dense[key] = mt
+        return self._dense
+
+    def _conv_nobias(self, x, conv, si, which):
+        mt = getattr(self, "_dense", {}).get(self._dense_key(si, which))
+        if mt is None:
+            return F.conv2d(x, conv.weight, None, padding=1)
+        return torch.mm(x.flatten(1), mt).view(x.shape[0], conv.out_channels, x.shape[2], x.shape[3])
+
     def forward_from_stem_fused(self, y, y_relu, ops):
         """Same network as forward_from_stem with the element-wise work fused: convolutions run without bias through
         PyTorch-ROCm, and `ops` (an engine: rp_nn_bias_relu / rp_nn_bias_residual / rp_nn_bias_pool) applies bias + ReLU,
         bias + skip (+ the next block's ReLU) and bias + max-pool in one pass each -- 4 kernels per residual block
-        instead of 7, the same float32 operations in the same order.  y_relu = relu(y).  Returns (softmax, tanh)."""
+        instead of 7, the same float32 operations in the same order.  Convolutions on <= 3x3 images run as one GEMM each
+        when refresh_dense() has been called.  y_relu = relu(y).  Returns (softmax, tanh)."""
         x, xr = y, y_relu
         for si, stage in enumerate(self.conv_seqs):
             if si > 0:
@@ -96,10 +132,10 @@ class BinPackingNNet(nn.Module):
                 x = c.new_empty((b, ch, (h + 1) // 2, (w + 1) // 2))
                 xr = torch.empty_like(x)
                 ops.nn_bias_pool(c, stage.conv.bias, x, xr)
-            for blk in (stage.res_block0, stage.res_block1):
-                c0 = F.conv2d(xr, blk.conv0.weight, None, padding=1)
+            for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
+                c0 = self._conv_nobias(xr, blk.conv0, si, "b%dc0" % bi)
                 ops.nn_bias_relu(c0, blk.conv0.bias)
-                c1 = F.conv2d(c0, blk.conv1.weight, None, padding=1)
+                c1 = self._conv_nobias(c0, blk.conv1, si, "b%dc1" % bi)
                 out, out_r = torch.empty_like(c1), torch.empty_like(c1)
                 ops.nn_bias_residual(c1, blk.conv1.bias, x, out, out_r)
                 x, xr = out, out_r

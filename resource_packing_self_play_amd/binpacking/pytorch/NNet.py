@@ -52,6 +52,11 @@ class NNetWrapper(NeuralNet):
         conv = self.nnet.conv_seqs[0].conv
         return conv.weight.detach().contiguous(), conv.bias.detach().contiguous()
 
+    def refresh_fused(self):
+        """Rebuilds the small-image convolution matrices after a weight update (in place: captured graphs stay valid)."""
+        if self.device.type == "cuda":
+            self.nnet.refresh_dense()
+
     def predict_from_stem(self, stem, stem_relu=None, ops=None):
         """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch.
         With `stem_relu` (= relu(stem), also written by rp_leaf_stem) and `ops` (the engine) the element-wise work runs

@@ -66,7 +66,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -80,6 +80,7 @@ class BatchedSelfPlay:
         self.use_graph = use_graph
         self.use_stem = bool(use_stem)
         self.fuse_elementwise = bool(fuse_elementwise) and self.use_stem
+        self.dense_small_convs = bool(dense_small_convs)
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
         self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0
@@ -103,6 +104,8 @@ class BatchedSelfPlay:
         """Warms the evaluator up (MIOpen picks its kernels on the first calls) and captures every group's wave -- the
         engine's kernels and the CNN's -- into one HIP graph each, so a wave costs one graph launch instead of ~40 kernel
         launches."""
+        if self.fuse_elementwise and self.dense_small_convs:
+            self.nnet.refresh_fused()
         if not self.use_graph:
             return
         for g in self.groups:
@@ -157,6 +160,9 @@ class BatchedSelfPlay:
         self.n_instances = item_wh.shape[0]
         k = len(self.groups)
         torch.cuda.synchronize(self.device)  # the evaluator's weights may just have been trained on another stream
+        if self.fuse_elementwise and self.dense_small_convs:
+            self.nnet.refresh_fused()
+            torch.cuda.synchronize(self.device)
         for g in self.groups:
             wh_g = np.ascontiguousarray(item_wh[g.index::k]); area_g = np.ascontiguousarray(total_area[g.index::k])
             with torch.cuda.stream(g.stream):

@@ -164,7 +164,7 @@ def test_leaf_planes_match_getBinItem():
         for step in range(30):
             n = eng.search_step()
             if n == 0:
-                break
+                continue  # between two moves
             eng.leaf_planes(buf.data_ptr(), games)
             rows, rem, slots = eng.leaf_states(n)
             got = buf.cpu().numpy()

@@ -162,10 +162,12 @@ def test_engine_stem_matches_conv_and_pool(name):
     planes = torch.zeros((games, N + 1, H, W), device="cuda"); stem = torch.zeros((games, 16, (H + 1) // 2, (W + 1) // 2), device="cuda")
     conv = net.nnet.conv_seqs[0].conv
     worst_stem = worst_pi = 0.0
+    checked = 0
     for step in range(60):
         n = eng.search_step()
         if n == 0:
-            break
+            continue  # every slot is between two moves (played at the start of the next step)
+        checked += 1
         eng.leaf_planes(planes.data_ptr(), games); eng.leaf_stem(stem.data_ptr(), games)
         with torch.no_grad():
             want = F.max_pool2d(conv(planes[:n]), kernel_size=3, stride=2, padding=1)
@@ -174,7 +176,7 @@ def test_engine_stem_matches_conv_and_pool(name):
         worst_pi = max(worst_pi, float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max()))
         eng.commit_eval(pi_a.data_ptr(), v_a.data_ptr()) if n == games else eng.commit_eval_host(pi_a.cpu().numpy(), v_a.cpu().numpy())
     print("stem max |delta| %.3e, pi/v max |delta| %.3e" % (worst_stem, worst_pi))
-    assert step > 20
+    assert checked > 20
     # The stem itself agrees with conv + pool to ~1e-6 (summation order).  Seeded nets carry that to 3e-8 on pi / v; the trained
     # 15x15 checkpoint amplifies a 1.4e-6 first-layer difference to 1.6e-4 in pi (its logits are peaked: PyTorch CPU alone moves
     # 3.8e-5 between batch shapes, tests/test_nnet_cpu.py), so it is held to 5e-4; use_stem=False gives the dense path.
@@ -200,6 +202,14 @@ def test_fused_elementwise_forward_matches_plain_forward(name):
     dpi, dv = float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max())
     print("fused vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
     assert dpi <= 1e-6 and dv <= 1e-6
+    net.refresh_fused()  # <= 3x3-image convolutions as GEMMs
+    assert len(net.nnet._dense) >= 4
+    pi_c, v_c = net.predict_from_stem(y, torch.relu(y), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_c).abs().max()), float((v_a - v_c).abs().max())
+    print("fused+dense vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-6
+    net.nnet._dense.clear()
     # the three kernels on their own
     x = torch.randn(33, 32, 5, 5, device="cuda"); b = torch.randn(32, device="cuda"); r = torch.randn_like(x)
     want = torch.relu(x + b.view(1, -1, 1, 1))
