@@ -14,13 +14,14 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as torchrun sets them.  Returns (rank, world, local_rank)."""
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as torchrun sets them.  Returns (rank, world, local device index).
+    Rehearsal on a single-GPU box: RP_DIST_BACKEND=gloo RP_SINGLE_DEVICE=1 runs every rank on device 0 with gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("RP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
