@@ -188,3 +188,70 @@ def test_capacity_overflow_is_reported():
         run_until_idle(eng, evaluate)
     assert ei.value.code == _lib.ERR_CAPACITY
     eng.close()
+
+
+def _play_pool(W, H, N, sims, wh, games, step_cap, kind, salt, seed, buf):
+    from resource_packing_self_play_amd import _lib
+    eng = make_engine(W, H, N, games, sims, move_rule=_lib.MOVE_SAMPLE, seed=seed, tie_salt=salt, auto_restart=1)
+    eng.set_step_cap(step_cap)
+    eng.set_rank_buffer(buf)
+    area = np.full(len(wh), W * H, np.int32)
+    eng._ck(eng.L.rp_set_instance_pool(eng.h, len(wh), _lib._ptr(np.ascontiguousarray(wh)), _lib._ptr(area), 500))
+    eng._ck(eng.L.rp_begin_pool(eng.h))
+    run_until_idle(eng, host_evaluator(lambda s: kind, W * N, lambda s: salt))
+    ids, outcome, score, moves = eng.pop_finished()
+    order = np.argsort(ids)
+    c = eng.counters()
+    eng.close()
+    return ids[order], outcome[order], score[order], moves[order], c
+
+
+def test_results_do_not_depend_on_slot_count_or_step_cap():
+    """Scheduling independence: the same pool of instances through 24, 7 or 5 slots, with or without the per-launch simulation
+    cap, finishes with identical episodes and identical engine counters; a sample is checked against the oracle."""
+    W, H, N, sims = 20, 20, 32, 48
+    rng = np.random.default_rng(77)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(24)])
+    buf = rng.uniform(0.7, 1.0, 50)
+    runs = [_play_pool(W, H, N, sims, wh, g, cap, "hashed", 11, 4242, buf) for g, cap in ((24, 0), (7, 3), (5, 1))]
+    for r in runs[1:]:
+        for a, b in zip(runs[0][:4], r[:4]):
+            assert np.array_equal(a, b)
+        for k in ("simulations", "expansions", "terminal_returns", "path_edges", "sum_valid_select", "sum_valid_leaf", "nodes", "moves", "episodes"):
+            assert runs[0][4][k] == r[4][k], k
+    assert list(runs[0][0]) == list(range(500, 524))
+    A = W * N
+    for g in (0, 9, 23):
+        m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: ev.table_eval("hashed", ev.pack_board(b), r, A, 11), lambda b, r: ev.tie_value(ev.pack_board(b), r, 11))
+        m.begin_episode(wh[g, :, 0], wh[g, :, 1], W * H, buf)
+        actions, _, o, s = m.play_episode(sims, policy=1, seed=4242, episode_id=500 + g, want_counts=False)
+        assert (runs[0][1][g], runs[0][2][g], runs[0][3][g]) == (o, s, len(actions))
+        m.close()
+
+
+def test_full_size_c3_episodes_match_oracle():
+    """BASELINE configs[2] at full size for a few games: 20x20 bin, 32 items, 400 simulations per move, whole episodes with
+    sampled moves -- every action, the outcome and the complete ~11 k-node tree of each game against the oracle."""
+    from resource_packing_self_play_amd import _lib
+    W, H, N, sims, games = 20, 20, 32, 400, 4
+    A = W * N
+    rng = np.random.default_rng(2020)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+    buf = rng.uniform(0.8, 1.0, 100)
+    eng = make_engine(W, H, N, games, sims, move_rule=_lib.MOVE_SAMPLE, seed=9, tie_salt=5)
+    eng.set_step_cap(16)
+    eng.set_rank_buffer(buf)
+    eng.begin_episodes(wh, np.full(games, W * H, np.int32), episode_id=np.arange(games) + 70)
+    run_until_idle(eng, host_evaluator(lambda s: "peaked", A, lambda s: 5))
+    ids, outcome, score, moves = eng.pop_finished()
+    fin = {int(i): (int(o), float(s), int(mv)) for i, o, s, mv in zip(ids, outcome, score, moves)}
+    for g in range(games):
+        m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: ev.table_eval("peaked", ev.pack_board(b), r, A, 5), lambda b, r: ev.tie_value(ev.pack_board(b), r, 5))
+        m.begin_episode(wh[g, :, 0], wh[g, :, 1], W * H, buf)
+        actions, _, o, s = m.play_episode(sims, policy=1, seed=9, episode_id=70 + g, want_counts=False)
+        assert fin[70 + g] == (o, s, len(actions)), g
+        tree = tree_as_dict(eng.dump_tree(g))
+        assert len(tree) > 3000
+        assert_trees_equal(tree, m.dump(), "full-size game %d" % g)
+        m.close()
+    eng.close()
