@@ -146,8 +146,10 @@ def main():
     ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
-    ap.add_argument("--edge-factor", type=int, default=128, help="legal-move arena = node arena x this (6 B per entry)")
-    ap.add_argument("--groups", type=int, default=2, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
+    ap.add_argument("--edge-factor", type=int, default=24, help="legal-move arena = node arena x this (6 B per entry)")
+    ap.add_argument("--vis-factor", type=float, default=1.5, help="visited-edge arena = node arena x this (26 B per entry)")
+    ap.add_argument("--no-reclaim", action="store_true", help="keep dead levels' arena chunks (needs ~5x the arena)")
+    ap.add_argument("--groups", type=int, default=3, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
     ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-fuse", action="store_true", help="leave bias / ReLU / skip / pool to PyTorch's own element-wise kernels")
@@ -189,7 +191,8 @@ def main():
     pool = a.pool or a.games
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
-                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense)
+                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
+                         reclaim=not a.no_reclaim, vis_cap=int(node_cap * a.vis_factor))
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)
@@ -301,7 +304,7 @@ def main():
                           "bytes_per_launch": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
                           "leaves_per_launch": leaves_per_wave, "slots_per_launch": sp.groups[0].G},
         "cpu_baseline": cpu_base,
-        "device_bytes": sp.device_bytes,
+        "device_bytes": sp.device_bytes, "arena_peak_per_slot": sp.arena_peak(),
     }
     if cpu_base:
         out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]

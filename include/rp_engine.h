@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 1
+#define RP_ABI_VERSION 2
 
 typedef enum rp_status {
     RP_OK = 0,
@@ -72,6 +72,9 @@ typedef struct rp_config {
     int32_t edge_cap;      /* per-game legal-move arena (one 6-byte entry per legal move of every node); 0 = automatic */
     int32_t move_rule;     /* rp_move_rule */
     int32_t auto_restart;  /* 1: a finished slot pulls the next instance from the pool set by rp_set_instance_pool */
+    int32_t reclaim;       /* 1: when a move is played, the arena chunks of the old root's level are recycled (its states
+                              are unreachable from then on); do not re-root to shallower states afterwards */
+    int32_t reserved0;
     uint64_t seed;         /* RNG seed for RP_MOVE_SAMPLE and the tie rule */
     uint64_t tie_salt;     /* salt of the deterministic stand-in for np.random.choice([1,-1]) (BinPackingGame.py:212) */
     int32_t device;        /* HIP device ordinal */
@@ -216,8 +219,11 @@ int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes
 int rp_examples_clear(rp_ctx *ctx);
 
 /* ---- inspection (parity tests) --------------------------------------------------------- */
-/* Sizes of slot g's tree: nodes and edges in use. */
+/* Sizes of slot g's tree: nodes in use and the span of its legal-move arena (the index range of rp_dump_tree's edge arrays). */
 int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out);
+/* High-water marks of the level arenas over all slots since create: chunks in use (legal-move runs, visited blocks) and
+ * the chunk sizes in entries (6 and 26 bytes per entry).  Sizing aid for edge_cap / vis_cap. */
+int rp_arena_peak(rp_ctx *ctx, int32_t *prior_chunks_out, int32_t *visited_chunks_out, int32_t *chunk_entries_out2);
 /* Host copy of slot g's tree.  Node i: rows u64[H], remaining u8[N], term i8 (0 / +-1 = Es),
  * term_kind u8, expanded u8, ns u32, edge_off u32, n_valid u32.  Edge e (one per legal move, dense view of the sparse
  * device layout): action u16, P f64, Q f64, nsa u32, q_kind u8, child u32 (0xFFFFFFFF = not linked yet). */

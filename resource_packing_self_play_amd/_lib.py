@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librp_engine.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MOVE_EXTERNAL, MOVE_ARGMAX_FIRST, MOVE_SAMPLE = 0, 1, 2
 PHASE_IDLE, PHASE_RUNNING, PHASE_WAIT_EVAL, PHASE_MOVE_READY, PHASE_EPISODE_DONE, PHASE_FAILED = range(6)
@@ -25,7 +25,8 @@ COUNTER_NAMES = ("simulations", "expansions", "terminal_returns", "path_edges", 
 class RpConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("W", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("games", C.c_int32),
                 ("sims", C.c_int32), ("cpuct", C.c_double), ("alpha", C.c_double), ("node_cap", C.c_int32),
-                ("edge_cap", C.c_int32), ("move_rule", C.c_int32), ("auto_restart", C.c_int32), ("seed", C.c_uint64),
+                ("edge_cap", C.c_int32), ("move_rule", C.c_int32), ("auto_restart", C.c_int32), ("reclaim", C.c_int32),
+                ("reserved0", C.c_int32), ("seed", C.c_uint64),
                 ("tie_salt", C.c_uint64), ("device", C.c_int32), ("vis_cap", C.c_int32), ("stream", C.c_void_p),
                 ("max_examples", C.c_int64)]
 
@@ -75,6 +76,7 @@ _SIGS = {
     "rp_examples_tensors": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "rp_examples_clear": (C.c_int, [_vp]),
     "rp_tree_size": (C.c_int, [_vp, _i32, _vp, _vp]),
+    "rp_arena_peak": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rp_dump_tree": (C.c_int, [_vp, _i32] + [_vp] * 14),
     "rp_selftest_sqrt": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rp_selftest_q_update": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -135,12 +137,12 @@ class Engine:
     """Thin object wrapper of one rp_ctx (one per process and GPU)."""
 
     def __init__(self, W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=MOVE_EXTERNAL, seed=0, tie_salt=0,
-                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0):
+                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0, reclaim=0):
         self.L = load()
         self.W, self.H, self.N, self.A, self.G, self.sims = int(W), int(H), int(N), int(W) * int(N), int(games), int(sims)
         self.move_rule = int(move_rule)
         cfg = RpConfig(ABI_VERSION, W, H, N, games, sims, float(cpuct), float(alpha), node_cap, edge_cap, move_rule,
-                       auto_restart, seed, tie_salt, device, vis_cap, stream or None, max_examples)
+                       auto_restart, 1 if reclaim else 0, 0, seed, tie_salt, device, vis_cap, stream or None, max_examples)
         h = _vp()
         rc = self.L.rp_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -329,6 +331,13 @@ class Engine:
         out = np.zeros(16, np.int64)
         self._ck(self.L.rp_counters(self.h, _ptr(out), 1 if reset else 0))
         return dict(zip(COUNTER_NAMES, out.tolist()))
+
+    def arena_peak(self):
+        """-> dict: peak chunks in use over all slots and the bytes that is, for the legal-move and the visited arenas."""
+        a, b = _i32(0), _i32(0)
+        ce = (_i32 * 2)()
+        self._ck(self.L.rp_arena_peak(self.h, C.byref(a), C.byref(b), ce))
+        return {"prior_chunks": a.value, "visited_chunks": b.value, "prior_bytes": a.value * ce[0] * 6, "visited_bytes": b.value * ce[1] * 26}
 
     def tree_size(self, slot):
         a, b = _i32(0), _i32(0)

@@ -57,7 +57,8 @@ struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
     u16 vis_cap;    // entries allocated (0 until the node is first selected at)
     int8_t term;    // Es[s]: 0 not ended, +1 / -1 ranked outcome (:78-83)
     u8 flags;       // bit 0 expanded (s in Ps), bit 1 uniform-fallback prior (:93-100), bits 2-3 kind of term
-    u32 pad;
+    u8 depth;       // items already placed in this state = level of the node in the game
+    u8 pad[3];
     double norm;    // np.sum(Ps[s]) that renormalises the masked prior (:90-92), or the fallback's sum (:100)
 };
 #define HF_EXPANDED 1u
@@ -66,6 +67,8 @@ __host__ __device__ inline u32 hdr_term_kind(const NodeHdr &h) { return (h.flags
 
 struct DP {  // device view of a context, passed by value to every kernel
     int W, H, N, A, G, sims, node_cap, edge_cap, vis_cap, table_cap, KW, RW, RMW, move_rule;
+    int reclaim;   // 1: a level's legal-move runs and visited blocks are recycled once the root has moved past it
+    int pchunk, n_pchunks, vchunk, n_vchunks;  // level arenas: entries per chunk, chunks per slot
     int step_cap;  // max simulations a slot runs in one k_search launch (0 = until it needs the evaluator)
     u32 magicW;  // a / W == (a * magicW) >> 20 for a < 8192
     double cpuct;
@@ -75,7 +78,12 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *total_area, *max_h;
     double *bl;     // R2 threshold snapshot taken when the episode began
     int *has_buf;
-    u32 *root, *n_nodes, *n_edges, *n_vis;
+    u32 *root, *n_nodes;
+    // level arenas (one for legal-move runs, one for visited blocks): per slot and level the chunk being filled, its fill, the
+    // level's chunk list; per slot a stack of recycled chunks and the count of never-used ones
+    u16 *pa_cur, *pa_head, *pa_next, *pa_stack, *va_cur, *va_head, *va_next, *va_stack;
+    u32 *pa_used, *pa_tf, *va_used, *va_tf;
+    u32 *peak_chunks;  // [2] high-water marks over all slots (sizing aid)
     int *phase, *sims_done, *moves;
     u64 *episode;
     u32 *leaf_node;
@@ -326,6 +334,51 @@ __device__ __forceinline__ void q_update(double &q, u32 &kind, u32 n, double v, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Level arena: bump allocation in fixed-size chunks, one open chunk per game level (number of items placed).  A state of
+// level d can only be reached while the root's level is below d, so once the root has moved past a level every run / block
+// of that level is dead and its chunks go back to the slot's stack (DP::reclaim).  All bookkeeping is done by lane 0 of the
+// slot's wave; the result is broadcast.
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    u32 chunk, n_chunks;
+    u16 *cur, *head, *next, *stack;  // cur/head: [N+1] per level; next/stack: [n_chunks]
+    u32 *used;                       // [N+1]
+    u32 *tf;                         // [0] chunks on the stack, [1] chunks never used yet
+};
+// offset of a run that can hold `need` entries at level d (the level's open chunk, or a new one); NONE32 when the arena is full
+__device__ u32 arena_reserve(const Arena &a, int d, u32 need, u32 *room) {
+    u32 off = NONE32, left = 0;
+    if (lane_id() == 0) {
+        u32 c = a.cur[d], used = a.used[d];
+        if (c == 0xFFFFu || used + need > a.chunk) {
+            u32 top = a.tf[0];
+            if (top > 0) { c = a.stack[top - 1]; a.tf[0] = top - 1; }
+            else { u32 f = a.tf[1]; if (f < a.n_chunks) { c = f; a.tf[1] = f + 1; } else c = 0xFFFFu; }
+            if (c != 0xFFFFu) { a.next[c] = a.head[d]; a.head[d] = (u16)c; a.cur[d] = (u16)c; a.used[d] = 0; used = 0; }
+        }
+        if (c != 0xFFFFu && need <= a.chunk) { off = c * a.chunk + used; left = a.chunk - used; }
+    }
+    *room = __shfl(left, 0);
+    return __shfl(off, 0);
+}
+__device__ void arena_commit(const Arena &a, int d, u32 n) {
+    if (lane_id() == 0) a.used[d] += n;
+}
+__device__ void arena_free_level(const Arena &a, int d) {
+    if (lane_id() == 0) {
+        u32 c = a.head[d], top = a.tf[0];
+        while (c != 0xFFFFu) { a.stack[top++] = (u16)c; c = a.next[c]; }
+        a.tf[0] = top;
+        a.head[d] = 0xFFFFu; a.cur[d] = 0xFFFFu; a.used[d] = 0;
+    }
+}
+__device__ void arena_reset(const Arena &a, int levels) {
+    for (int d = lane_id(); d < levels; d += 64) { a.cur[d] = 0xFFFFu; a.head[d] = 0xFFFFu; a.used[d] = 0; }
+    if (lane_id() == 0) { a.tf[0] = 0; a.tf[1] = 0; }
+}
+__device__ u32 arena_in_use(const Arena &a) { return a.tf[1] - a.tf[0]; }
+
+// ------------------------------------------------------------------------------------------------
 // slot-local tree
 // ------------------------------------------------------------------------------------------------
 template <typename row_t> struct Tree {
@@ -340,7 +393,8 @@ template <typename row_t> struct Tree {
     double *vQ, *vP;
     u64 *table;
     const u8 *wh;
-    u32 n_nodes, n_edges, n_vis;
+    Arena pa, va;  // legal-move runs, visited blocks
+    u32 n_nodes;
     u64 c_probes, c_keybytes, c_nodes;
 
     __device__ Tree(const DP &p_, int g_) : p(p_), g(g_) {
@@ -352,13 +406,24 @@ template <typename row_t> struct Tree {
         table = p.table + (size_t)g * p.table_cap;
         wh = p.item_wh + (size_t)g * p.N * 2;
         n_nodes = p.n_nodes[g];
-        n_edges = p.n_edges[g];
-        n_vis = p.n_vis[g];
+        const size_t lv = (size_t)g * (p.N + 1);
+        pa.chunk = p.pchunk; pa.n_chunks = p.n_pchunks;
+        pa.cur = p.pa_cur + lv; pa.head = p.pa_head + lv; pa.used = p.pa_used + lv;
+        pa.next = p.pa_next + (size_t)g * p.n_pchunks; pa.stack = p.pa_stack + (size_t)g * p.n_pchunks; pa.tf = p.pa_tf + (size_t)g * 2;
+        va.chunk = p.vchunk; va.n_chunks = p.n_vchunks;
+        va.cur = p.va_cur + lv; va.head = p.va_head + lv; va.used = p.va_used + lv;
+        va.next = p.va_next + (size_t)g * p.n_vchunks; va.stack = p.va_stack + (size_t)g * p.n_vchunks; va.tf = p.va_tf + (size_t)g * 2;
         c_probes = c_keybytes = c_nodes = 0;
     }
     __device__ void store_sizes() {
-        if (lane_id() == 0) { p.n_nodes[g] = n_nodes; p.n_edges[g] = n_edges; p.n_vis[g] = n_vis; }
+        if (lane_id() == 0) {
+            p.n_nodes[g] = n_nodes;
+            atomicMax(p.peak_chunks + 0, arena_in_use(pa));
+            atomicMax(p.peak_chunks + 1, arena_in_use(va));
+        }
     }
+    __device__ void reset_arenas() { arena_reset(pa, p.N + 1); arena_reset(va, p.N + 1); }
+    static __device__ __forceinline__ int level_of(int N, u64 rem0, u64 rem1) { return N - __popcll(rem0) - __popcll(rem1); }
 
     // key of a node -> lane-resident rows + uniform remaining words
     __device__ void load_key(u32 node, row_t &myrow, u64 &rem0, u64 &rem1) const {
@@ -425,16 +490,25 @@ template <typename row_t> struct Tree {
         }
         const u32 id = n_nodes;
         store_key(id, myrow, rem0, rem1);
+        const int level = level_of(p.N, rem0, rem1);
+        u32 need = (u32)(p.N - level) * (u32)p.W, room;  // at most one legal move per (unplaced item, column)
+        if (need > (u32)p.A) need = (u32)p.A;
+        const u32 off = arena_reserve(pa, level, need, &room);
+        if (off == NONE32) {
+            if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
+            return NONE32;
+        }
         ValidSink sink;
-        sink.act = pAct + n_edges; sink.mask = nullptr; sink.cap = p.edge_cap - (int)n_edges;
+        sink.act = pAct + off; sink.mask = nullptr; sink.cap = (int)room;
         int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
         if (nv < 0) {
             if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
             return NONE32;
         }
+        arena_commit(pa, level, (u32)nv);
         NodeHdr hd;
-        hd.ns = 0; hd.prior_off = n_edges; hd.vis_off = 0; hd.n_valid = (u16)nv; hd.vis_n = 0; hd.vis_cap = 0; hd.term = 0;
-        hd.flags = (u8)(RP_KIND_WEAK << 2); hd.pad = 0; hd.norm = 0.0;
+        hd.ns = 0; hd.prior_off = off; hd.vis_off = 0; hd.n_valid = (u16)nv; hd.vis_n = 0; hd.vis_cap = 0; hd.term = 0;
+        hd.flags = (u8)(RP_KIND_WEAK << 2); hd.depth = (u8)level; hd.pad[0] = hd.pad[1] = hd.pad[2] = 0; hd.norm = 0.0;
         if (nv == 0) {  // no legal move: game over (BinPackingGame.py:112-114)
             double r;
             int e = ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
@@ -446,7 +520,6 @@ template <typename row_t> struct Tree {
             table[insert_slot] = ((u64)(u32)(h >> 32) << 32) | (u64)(id + 1u);
         }
         n_nodes++;
-        n_edges += (u32)nv;
         c_nodes++;
         return id;
     }
@@ -477,18 +550,18 @@ template <typename row_t> struct Tree {
     // The visited-edge block of a node grows by doubling inside the slot's arena (old blocks are abandoned: at most the
     // live size again).  Returns false on arena overflow.
     __device__ bool grow_visited(u32 node, NodeHdr &hd) {
-        u32 cap = hd.vis_cap ? 2u * hd.vis_cap : 2u;
+        u32 cap = hd.vis_cap ? 2u * hd.vis_cap : 2u, room;
         if (cap > hd.n_valid) cap = hd.n_valid;
-        if (n_vis + cap > (u32)p.vis_cap) {
+        const u32 dst = arena_reserve(va, hd.depth, cap, &room);
+        if (dst == NONE32) {
             if (lane_id() == 0) set_error(p, ERR_VIS_CAP);
             return false;
         }
-        const u32 dst = n_vis;
+        arena_commit(va, hd.depth, cap);
         for (u32 j = lane_id(); j < hd.vis_n; j += 64) {
             u32 s = hd.vis_off + j, d = dst + j;
             vIdx[d] = vIdx[s]; vN[d] = vN[s]; vQ[d] = vQ[s]; vP[d] = vP[s]; vChild[d] = vChild[s];
         }
-        n_vis += cap;
         hd.vis_off = dst; hd.vis_cap = (u16)cap;
         if (lane_id() == 0) { hdr[node].vis_off = dst; hdr[node].vis_cap = (u16)cap; }
         wave_sync();
@@ -670,6 +743,10 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
             set_error(p, ERR_EXAMPLES_CAP);
         }
     }
+    if (p.reclaim) {  // everything at the old root's level is unreachable from now on
+        arena_free_level(t.pa, hd.depth);
+        arena_free_level(t.va, hd.depth);
+    }
     root = child;
     c[CNT_MOVES]++;
     NodeHdr ch = t.hdr[child];
@@ -726,7 +803,8 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
         p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;
         p.last_outcome[g] = 0; p.last_score[g] = 0.0;
     }
-    t.n_nodes = 0; t.n_edges = 0; t.n_vis = 0;
+    t.n_nodes = 0;
+    t.reset_arenas();
     wave_sync();
     bool was_new;
     row_t myrow = 0;
@@ -1145,13 +1223,14 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
         u64 *tab = p.table + (size_t)g * p.table_cap;
         for (int s = lane; s < p.table_cap; s += 64) tab[s] = 0ull;
         if (lane == 0) {
-            p.n_nodes[g] = 0; p.n_edges[g] = 0; p.n_vis[g] = 0; p.moves[g] = 0;
+            p.n_nodes[g] = 0; p.moves[g] = 0;
             p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;  // rewards_list snapshot for this episode
             p.last_outcome[g] = 0; p.last_score[g] = 0.0;
         }
         wave_sync();
     }
     Tree<row_t> t(p, g);
+    if (clear_tree) { t.reset_arenas(); wave_sync(); }
     row_t myrow; u64 rem0, rem1;
     if (rows) {
         load_host_state<row_t>(p, rows + (size_t)k * p.H, rem + (size_t)k * p.N, myrow, rem0, rem1);
@@ -1516,6 +1595,16 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (cfg->N + 1) + 2;
     d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 96) + d.A;
     d.vis_cap = cfg->vis_cap > 0 ? cfg->vis_cap : 6 * d.node_cap + 64;
+    // level arenas: a chunk must hold the largest run (A legal moves / a visited block of up to A entries)
+    auto pow2_at_least = [](int x) { int c = 1; while (c < x) c *= 2; return c; };
+    d.pchunk = std::max(4096, pow2_at_least(d.A));
+    d.vchunk = std::max(1024, pow2_at_least(d.A));
+    d.n_pchunks = std::max((d.edge_cap + d.pchunk - 1) / d.pchunk, cfg->N + 2);
+    d.n_vchunks = std::max((d.vis_cap + d.vchunk - 1) / d.vchunk, cfg->N + 2);
+    if (d.n_pchunks > 0xFFFE || d.n_vchunks > 0xFFFE) { delete ctx; return fail(nullptr, RP_ERR_ARG, "arena too large for 16-bit chunk ids"); }
+    d.edge_cap = d.n_pchunks * d.pchunk;
+    d.vis_cap = d.n_vchunks * d.vchunk;
+    d.reclaim = cfg->reclaim ? 1 : 0;
     int tc = 64;
     while (tc < 2 * d.node_cap) tc *= 2;
     d.table_cap = tc;
@@ -1532,7 +1621,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     int rc = RP_OK;
     auto A_ = [&](auto &ptr, size_t n) { if (rc == RP_OK) rc = dev_alloc(ctx, &ptr, n); };
     A_(d.item_wh, G * N * 2); A_(d.total_area, G); A_(d.max_h, G); A_(d.bl, G); A_(d.has_buf, G);
-    A_(d.root, G); A_(d.n_nodes, G); A_(d.n_edges, G); A_(d.n_vis, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
+    A_(d.root, G); A_(d.n_nodes, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
     A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
     A_(d.last_outcome, G); A_(d.last_score, G); A_(d.last_v, G); A_(d.last_vkind, G);
     A_(d.eval_count, 1); A_(d.eval_slot, G);
@@ -1540,6 +1629,9 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.pAct, G * d.edge_cap); A_(d.pPi, G * d.edge_cap);
     A_(d.vIdx, G * d.vis_cap); A_(d.vN, G * d.vis_cap); A_(d.vQ, G * d.vis_cap); A_(d.vP, G * d.vis_cap); A_(d.vChild, G * d.vis_cap);
     A_(d.table, G * d.table_cap);
+    A_(d.pa_cur, G * (N + 1)); A_(d.pa_head, G * (N + 1)); A_(d.pa_used, G * (N + 1)); A_(d.pa_next, G * d.n_pchunks); A_(d.pa_stack, G * d.n_pchunks); A_(d.pa_tf, G * 2);
+    A_(d.va_cur, G * (N + 1)); A_(d.va_head, G * (N + 1)); A_(d.va_used, G * (N + 1)); A_(d.va_next, G * d.n_vchunks); A_(d.va_stack, G * d.n_vchunks); A_(d.va_tf, G * 2);
+    A_(d.peak_chunks, 2);
     A_(d.g_bl, 1); A_(d.g_has_buf, 1); A_(d.counters, CNT_N); A_(d.error, 1);
     d.fin_cap = (int)std::max<size_t>(4 * G, 1024);
     A_(d.fin_count, 1); A_(d.fin_episode, d.fin_cap); A_(d.fin_outcome, d.fin_cap); A_(d.fin_moves, d.fin_cap); A_(d.fin_score, d.fin_cap);
@@ -1560,6 +1652,9 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         return fail(nullptr, rc, "rp_create: %s (needs about %.1f GiB of HBM)", msg.c_str(),
                     (double)(G * ((size_t)d.node_cap * (32 + 4 * d.KW) + (size_t)d.edge_cap * 6 + (size_t)d.vis_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
     }
+    // no chunk is open before the first episode begins
+    (void)hipMemsetAsync(d.pa_cur, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream); (void)hipMemsetAsync(d.pa_head, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream);
+    (void)hipMemsetAsync(d.va_cur, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream); (void)hipMemsetAsync(d.va_head, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream);
     d.n_leaves = (int)L;
     for (size_t k = 0; k < L; ++k) { d.leaf_lo[k] = (u16)llo[k]; d.leaf_n[k] = (u8)ln[k]; }
     for (size_t k = 0; k < S; ++k) { d.sched_dst[k] = (u8)sd[k]; d.sched_src[k] = (u8)ss[k]; }
@@ -2019,8 +2114,18 @@ extern "C" int rp_counters(rp_ctx *ctx, int64_t *out16, int32_t reset) {
 extern "C" int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out) {
     if (!ctx || slot < 0 || slot >= ctx->d.G || !n_nodes_out || !n_edges_out) return fail(ctx, RP_ERR_ARG, "rp_tree_size: bad argument");
     HIPCHK(ctx, hipMemcpyAsync(n_nodes_out, ctx->d.n_nodes + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(n_edges_out, ctx->d.n_edges + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_edges_out = ctx->d.edge_cap;  // legal-move runs live in level chunks: the dense edge view spans the slot's whole arena
+    return RP_OK;
+}
+
+extern "C" int rp_arena_peak(rp_ctx *ctx, int32_t *prior_chunks_out, int32_t *visited_chunks_out, int32_t *chunk_entries_out2) {
+    if (!ctx || !prior_chunks_out || !visited_chunks_out) return fail(ctx, RP_ERR_ARG, "rp_arena_peak: bad argument");
+    u32 pk[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(pk, ctx->d.peak_chunks, sizeof pk, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *prior_chunks_out = (int)pk[0]; *visited_chunks_out = (int)pk[1];
+    if (chunk_entries_out2) { chunk_entries_out2[0] = ctx->d.pchunk; chunk_entries_out2[1] = ctx->d.vchunk; }
     return RP_OK;
 }
 
@@ -2032,8 +2137,7 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
     int nn = 0, ne = 0;
     int rc = rp_tree_size(ctx, slot, &nn, &ne);
     if (rc != RP_OK) return rc;
-    int nv = 0;
-    HIPCHK(ctx, hipMemcpy(&nv, d.n_vis + slot, sizeof(int), hipMemcpyDeviceToHost));
+    const int nv = d.vis_cap;
     std::vector<NodeHdr> hdr(nn);
     std::vector<u32> key((size_t)nn * d.KW), vN(nv), vC(nv);
     std::vector<u16> vI(nv);
@@ -2058,6 +2162,8 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
         node_term[i] = h.term; node_term_kind[i] = (u8)hdr_term_kind(h); node_expanded[i] = (h.flags & HF_EXPANDED) ? 1 : 0;
         node_ns[i] = h.ns; node_edge_off[i] = h.prior_off; node_n_valid[i] = h.n_valid;
         // dense per-legal-move view: the prior as the search would compute it, statistics only where an edge was visited
+        if ((size_t)h.prior_off + h.n_valid > (size_t)ne || (h.vis_n && (size_t)h.vis_off + h.vis_n > (size_t)nv))
+            return fail(ctx, RP_ERR_STATE, "rp_dump_tree: node %d points outside its arena", i);
         for (u32 e = h.prior_off; e < h.prior_off + h.n_valid; ++e) {
             double x = (double)pi[e] * 1.0;
             edge_p[e] = !(h.flags & HF_EXPANDED) ? 0.0 : ((h.flags & HF_FALLBACK) ? (x + 1.0) / h.norm : x / h.norm);

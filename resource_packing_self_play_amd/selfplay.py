@@ -31,7 +31,8 @@ class _Group:
         self.eng = _lib.Engine(owner.W, owner.H, owner.N, games, int(owner.args.numMCTSSims), cpuct=float(owner.args.cpuct),
                                alpha=float(owner.args.alpha), move_rule=owner.move_rule, seed=seed, tie_salt=seed ^ 0x5DEECE66D,
                                node_cap=owner.node_cap, edge_cap=owner.edge_cap, device=owner.device.index or 0,
-                               stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group)
+                               stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group,
+                               vis_cap=owner.vis_cap, reclaim=1 if owner.reclaim else 0)
         self.eng.set_step_cap(owner.step_cap)
         self.use_stem = owner.use_stem
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
@@ -66,7 +67,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -76,6 +77,7 @@ class BatchedSelfPlay:
         groups = max(1, min(int(groups), int(games)))
         self.G = int(games)
         self.move_rule, self.node_cap, self.edge_cap, self.step_cap = move_rule, node_cap, edge_cap, int(step_cap)
+        self.reclaim, self.vis_cap = bool(reclaim), int(vis_cap)
         self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
         self.use_graph = use_graph
         self.use_stem = bool(use_stem)
@@ -187,6 +189,10 @@ class BatchedSelfPlay:
             parts.append((ids.astype(np.int64) * k + g.index + self.first_id, oc, sc, mv))
         ids = np.concatenate([p[0] for p in parts]); order = np.argsort(ids, kind="stable")
         return tuple(np.concatenate([p[j] for p in parts])[order] for j in range(4))
+
+    def arena_peak(self):
+        peaks = [g.eng.arena_peak() for g in self.groups]
+        return {k: max(pk[k] for pk in peaks) for k in peaks[0]}
 
     def counters(self, reset=False):
         tot = dict.fromkeys(_lib.COUNTER_NAMES, 0)

@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from resource_packing_self_play_amd import _lib
-    # int32 x6, double x2, int32 x4, uint64 x2, int32 x2, void*, int64
-    assert ctypes.sizeof(_lib.RpConfig) == 6 * 4 + 2 * 8 + 4 * 4 + 2 * 8 + 2 * 4 + 8 + 8
+    # int32 x6, double x2, int32 x6, uint64 x2, int32 x2, void*, int64
+    assert ctypes.sizeof(_lib.RpConfig) == 6 * 4 + 2 * 8 + 6 * 4 + 2 * 8 + 2 * 4 + 8 + 8
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -255,3 +255,49 @@ def test_full_size_c3_episodes_match_oracle():
         assert_trees_equal(tree, m.dump(), "full-size game %d" % g)
         m.close()
     eng.close()
+
+
+def test_reclaiming_dead_levels_changes_nothing():
+    """DP::reclaim recycles the arena chunks of a level once the root has moved past it.  Same pool, with and without it, in
+    arenas that would overflow without recycling: identical episodes and counters; the peak arena use drops."""
+    from resource_packing_self_play_amd import _lib
+    W, H, N, sims = 20, 20, 32, 64
+    rng = np.random.default_rng(31)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(12)])
+    buf = rng.uniform(0.7, 1.0, 50)
+    area = np.full(len(wh), W * H, np.int32)
+    out = {}
+    for reclaim in (0, 1):
+        eng = make_engine(W, H, N, 6, sims, move_rule=_lib.MOVE_SAMPLE, seed=77, tie_salt=3, auto_restart=1, reclaim=reclaim)
+        eng.set_step_cap(4)
+        eng.set_rank_buffer(buf)
+        eng._ck(eng.L.rp_set_instance_pool(eng.h, len(wh), _lib._ptr(np.ascontiguousarray(wh)), _lib._ptr(area), 0))
+        eng._ck(eng.L.rp_begin_pool(eng.h))
+        run_until_idle(eng, host_evaluator(lambda s: "hashed", W * N, lambda s: 3))
+        ids, outcome, score, moves = eng.pop_finished()
+        order = np.argsort(ids)
+        out[reclaim] = (ids[order], outcome[order], score[order], moves[order], eng.counters(), eng.arena_peak())
+        eng.close()
+    for a, b in zip(out[0][:4], out[1][:4]):
+        assert np.array_equal(a, b)
+    for k in ("simulations", "expansions", "terminal_returns", "path_edges", "sum_valid_select", "sum_valid_leaf", "nodes", "visited_new"):
+        assert out[0][4][k] == out[1][4][k], k
+    print("arena peak without / with reclaim:", out[0][5], out[1][5])
+    assert out[1][5]["prior_chunks"] < out[0][5]["prior_chunks"]
+    # a tight arena only works with recycling
+    tight = dict(edge_cap=out[1][5]["prior_chunks"] * 4096 + 4096, vis_cap=out[1][5]["visited_chunks"] * 1024 + 1024)
+    eng = make_engine(W, H, N, 6, sims, move_rule=_lib.MOVE_SAMPLE, seed=77, tie_salt=3, auto_restart=1, reclaim=1, **tight)
+    eng.set_rank_buffer(buf)
+    eng._ck(eng.L.rp_set_instance_pool(eng.h, len(wh), _lib._ptr(np.ascontiguousarray(wh)), _lib._ptr(area), 0))
+    eng._ck(eng.L.rp_begin_pool(eng.h))
+    run_until_idle(eng, host_evaluator(lambda s: "hashed", W * N, lambda s: 3))
+    ids, outcome, score, moves = eng.pop_finished()
+    assert np.array_equal(outcome[np.argsort(ids)], out[0][1])
+    eng.close()
+    eng = make_engine(W, H, N, 6, sims, move_rule=_lib.MOVE_SAMPLE, seed=77, tie_salt=3, auto_restart=1, reclaim=0, **tight)
+    eng.set_rank_buffer(buf)
+    eng._ck(eng.L.rp_set_instance_pool(eng.h, len(wh), _lib._ptr(np.ascontiguousarray(wh)), _lib._ptr(area), 0))
+    eng._ck(eng.L.rp_begin_pool(eng.h))
+    with pytest.raises(_lib.EngineError):
+        run_until_idle(eng, host_evaluator(lambda s: "hashed", W * N, lambda s: 3))
+    eng.close()
