@@ -1599,8 +1599,10 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     auto pow2_at_least = [](int x) { int c = 1; while (c < x) c *= 2; return c; };
     d.pchunk = std::max(4096, pow2_at_least(d.A));
     d.vchunk = std::max(1024, pow2_at_least(d.A));
-    d.n_pchunks = std::max((d.edge_cap + d.pchunk - 1) / d.pchunk, cfg->N + 2);
-    d.n_vchunks = std::max((d.vis_cap + d.vchunk - 1) / d.vchunk, cfg->N + 2);
+    // automatic sizes: every level keeps one partly filled chunk open, so add a chunk per level to the packed estimate
+    d.n_pchunks = (d.edge_cap + d.pchunk - 1) / d.pchunk + (cfg->edge_cap > 0 ? 0 : cfg->N + 1);
+    d.n_vchunks = (d.vis_cap + d.vchunk - 1) / d.vchunk + (cfg->vis_cap > 0 ? 0 : cfg->N + 1);
+    d.n_pchunks = std::max(d.n_pchunks, 2); d.n_vchunks = std::max(d.n_vchunks, 2);
     if (d.n_pchunks > 0xFFFE || d.n_vchunks > 0xFFFE) { delete ctx; return fail(nullptr, RP_ERR_ARG, "arena too large for 16-bit chunk ids"); }
     d.edge_cap = d.n_pchunks * d.pchunk;
     d.vis_cap = d.n_vchunks * d.vchunk;
