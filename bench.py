@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--games", type=int, default=8192, help="concurrent game slots per GPU")
+    ap.add_argument("--games", type=int, default=32768, help="concurrent game slots per GPU (BASELINE configs[2]: 32k concurrent games)")
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--edge-factor", type=int, default=24, help="legal-move arena = node arena x this (6 B per entry)")
