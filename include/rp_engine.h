@@ -124,6 +124,12 @@ int rp_begin_episodes(rp_ctx *ctx, int32_t first, int32_t count, const uint8_t *
 int rp_set_instance_pool(rp_ctx *ctx, int64_t n_instances, const uint8_t *item_wh /*[n][N][2]*/,
                          const int32_t *total_area /*[n]*/, uint64_t first_id);
 int rp_begin_pool(rp_ctx *ctx);
+/* ItemsGenerator.items_generator(seed) (BinPackingGame.py:257-285) on device: guillotine cuts of the bin_w x bin_h rectangle
+ * into N items, bit-identical to the reference's NumPy stream (np.random.seed = MT19937 init_genrand, legacy randint = masked
+ * rejection on 32-bit draws).  rp_generate_items returns the (w, h) pairs to the host; rp_set_instance_pool_seeds fills the
+ * auto_restart pool directly on device (total area bin_w * bin_h as CoachBPP.py:119). */
+int rp_generate_items(rp_ctx *ctx, int64_t n, const uint32_t *seeds /*[n]*/, int32_t bin_w, int32_t bin_h, uint8_t *item_wh_out /*[n][N][2]*/);
+int rp_set_instance_pool_seeds(rp_ctx *ctx, int64_t n_instances, const uint32_t *seeds, int32_t bin_w, int32_t bin_h, uint64_t first_id);
 /* R2 buffer snapshot (rewards_list argument of MCTS.getActionProb / getGameEnded, CoachBPP.py:76-91):
  * the threshold sorted[int(floor(len*alpha))-1] is recomputed and used by every slot from now on. */
 int rp_set_rank_buffer(rp_ctx *ctx, const double *rewards, int32_t n);

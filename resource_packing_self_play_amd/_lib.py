@@ -50,6 +50,8 @@ _SIGS = {
     "rp_begin_episodes": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "rp_set_instance_pool": (C.c_int, [_vp, _i64, _vp, _vp, C.c_uint64]),
     "rp_begin_pool": (C.c_int, [_vp]),
+    "rp_generate_items": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _vp]),
+    "rp_set_instance_pool_seeds": (C.c_int, [_vp, _i64, _vp, _i32, _i32, C.c_uint64]),
     "rp_set_rank_buffer": (C.c_int, [_vp, _vp, _i32]),
     "rp_set_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rp_set_stream": (C.c_int, [_vp, _vp]),
@@ -206,6 +208,17 @@ class Engine:
         item_wh = _arr(item_wh, np.uint8, (count, self.N, 2)); total_area = _arr(total_area, np.int32, (count,))
         ids = None if episode_id is None else _arr(episode_id, np.uint64, (count,))
         self._ck(self.L.rp_begin_episodes(self.h, first, count, _ptr(item_wh), _ptr(total_area), _ptr(ids)))
+
+    def generate_items(self, seeds, bin_w=None, bin_h=None):
+        """ItemsGenerator.items_generator for every seed, on device -> uint8 [n, N, 2] (w, h)."""
+        seeds = _arr(seeds, np.uint32).reshape(-1)
+        out = np.empty((seeds.shape[0], self.N, 2), np.uint8)
+        self._ck(self.L.rp_generate_items(self.h, seeds.shape[0], _ptr(seeds), int(bin_w or self.W), int(bin_h or self.H), _ptr(out)))
+        return out
+
+    def set_instance_pool_seeds(self, seeds, bin_w=None, bin_h=None, first_id=0):
+        seeds = _arr(seeds, np.uint32).reshape(-1)
+        self._ck(self.L.rp_set_instance_pool_seeds(self.h, seeds.shape[0], _ptr(seeds), int(bin_w or self.W), int(bin_h or self.H), int(first_id)))
 
     def set_roots(self, rows, remaining, first=0):
         rows = _arr(rows, np.uint64); count = rows.shape[0]

@@ -1324,6 +1324,80 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, long lo
     if (lane == 0) value[k] = (float)p.ex_value[idx];
 }
 
+// ------------------------------------------------------------------------------------------------
+// ItemsGenerator.items_generator(seed) on device (BinPackingGame.py:257-285): np.random.seed(seed) is MT19937's
+// init_genrand, np.random.randint(lo, hi) of the legacy RandomState draws 32-bit outputs masked to the next power of two
+// and rejects values above hi-1-lo (no draw at all when the range has one value).  One thread per instance; the 624-word
+// state is word-major in HBM so a wave's accesses coalesce.
+// ------------------------------------------------------------------------------------------------
+struct Mt {
+    u32 *st;      // st[i * stride]
+    size_t stride;
+    int pos;
+    __device__ u32 &at(int i) { return st[(size_t)i * stride]; }
+    __device__ void seed(u32 s) {
+        for (int i = 0; i < 624; ++i) { at(i) = s; s = 1812433253u * (s ^ (s >> 30)) + (u32)i + 1u; }
+        pos = 624;
+    }
+    __device__ void twist() {
+        const u32 UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+        int k = 0;
+        for (; k < 624 - 397; ++k) { u32 y = (at(k) & UP) | (at(k + 1) & LO); at(k) = at(k + 397) ^ (y >> 1) ^ ((y & 1u) ? MA : 0u); }
+        for (; k < 623; ++k) { u32 y = (at(k) & UP) | (at(k + 1) & LO); at(k) = at(k - 227) ^ (y >> 1) ^ ((y & 1u) ? MA : 0u); }
+        u32 y = (at(623) & UP) | (at(0) & LO);
+        at(623) = at(396) ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+        pos = 0;
+    }
+    __device__ u32 next() {
+        if (pos == 624) twist();
+        u32 y = at(pos++);
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    // legacy RandomState.randint(lo, hi): lo + masked rejection sample of [0, hi-1-lo]
+    __device__ int randint(int lo, int hi) {
+        u32 rng = (u32)(hi - 1 - lo);
+        if (rng == 0) return lo;
+        u32 mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        u32 v;
+        while ((v = next() & mask) > rng) {}
+        return lo + (int)v;
+    }
+};
+__global__ void k_items_generator(long long n, int N, int bin_w, int bin_h, const u32 *seeds, u32 *mt_scratch, u8 *out_wh) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Mt mt; mt.st = mt_scratch + t; mt.stride = (size_t)n;
+    mt.seed(seeds[t]);
+    u8 L[128][4];  // [w, h, a, b]
+    int len = 1;
+    L[0][0] = (u8)bin_w; L[0][1] = (u8)bin_h; L[0][2] = 0; L[0][3] = 0;
+    while (len < N) {
+        int axis = mt.randint(0, 2);
+        int idx = mt.randint(0, len);
+        int w = L[idx][0], h = L[idx][1], a = L[idx][2], b = L[idx][3];
+        u8 p0[4], p1[4];
+        if (axis == 0) {
+            if (w == 1) continue;
+            int cut = mt.randint(a + 1, a + w) - a;
+            p0[0] = (u8)cut; p0[1] = (u8)h; p0[2] = (u8)a; p0[3] = (u8)b;
+            p1[0] = (u8)(w - cut); p1[1] = (u8)h; p1[2] = (u8)(a + cut); p1[3] = (u8)b;
+        } else {
+            if (h == 1) continue;
+            int cut = mt.randint(b + 1, b + h) - b;
+            p0[0] = (u8)w; p0[1] = (u8)cut; p0[2] = (u8)a; p0[3] = (u8)b;
+            p1[0] = (u8)w; p1[1] = (u8)(h - cut); p1[2] = (u8)a; p1[3] = (u8)(b + cut);
+        }
+        for (int k = idx; k + 1 < len; ++k)  // item_list.pop(idx) after the two appends: the rest keeps its order
+            for (int q = 0; q < 4; ++q) L[k][q] = L[k + 1][q];
+        for (int q = 0; q < 4; ++q) { L[len - 1][q] = p0[q]; L[len][q] = p1[q]; }
+        len++;
+    }
+    u8 *o = out_wh + (size_t)t * N * 2;
+    for (int i = 0; i < N; ++i) { o[2 * i] = L[i][0]; o[2 * i + 1] = L[i][1]; }
+}
+
 // ---- stateless rule kernels (one wave per state) ----
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, u8 *mask, int *nvalid) {
@@ -2062,6 +2136,61 @@ extern "C" int rp_set_instance_pool(rp_ctx *ctx, int64_t n_instances, const uint
         HIPCHK(ctx, hipMemcpyAsync(ctx->pool_wh, item_wh, (size_t)n_instances * d.N * 2, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pool_area, total_area, (size_t)n_instances * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(ctx->pool_max_h, mh.data(), (size_t)n_instances * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemsetAsync(d.next_instance, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    d.pool_wh = ctx->pool_wh; d.pool_area = ctx->pool_area; d.pool_max_h = ctx->pool_max_h;
+    d.n_instances = n_instances; d.first_id = first_id;
+    return RP_OK;
+}
+
+// instances from generator seeds into a DEVICE buffer [n][N][2] (shared by rp_generate_items and rp_set_instance_pool_seeds)
+static int generate_items_dev(rp_ctx *ctx, int64_t n, const uint32_t *seeds_host, int bin_w, int bin_h, u8 *out_dev) {
+    const DP &d = ctx->d;
+    if (bin_w < 1 || bin_w > d.W || bin_h < 1 || bin_h > d.H || bin_w > 255 || bin_h > 255)
+        return fail(ctx, RP_ERR_ARG, "generator rectangle %dx%d does not fit the %dx%d grid", bin_w, bin_h, d.W, d.H);
+    if ((int64_t)bin_w * bin_h < d.N) return fail(ctx, RP_ERR_ARG, "a %dx%d rectangle cannot be cut into %d items", bin_w, bin_h, d.N);
+    Scratch s(ctx);
+    u32 *dseeds = s.up((const u32 *)seeds_host, (size_t)n); NEED(dseeds);
+    u32 *dmt = s.up((const u32 *)nullptr, (size_t)n * 624); NEED(dmt);
+    hipLaunchKernelGGL(k_items_generator, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (long long)n, d.N, bin_w, bin_h, (const u32 *)dseeds, dmt, out_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // scratch is freed on return
+    return RP_OK;
+}
+
+extern "C" int rp_generate_items(rp_ctx *ctx, int64_t n, const uint32_t *seeds, int32_t bin_w, int32_t bin_h, uint8_t *item_wh_out) {
+    if (!ctx || n < 0 || !seeds || !item_wh_out) return fail(ctx, RP_ERR_ARG, "rp_generate_items: bad argument");
+    if (n == 0) return RP_OK;
+    Scratch s(ctx);
+    u8 *dout = s.up((const u8 *)nullptr, (size_t)n * ctx->d.N * 2); NEED(dout);
+    int rc = generate_items_dev(ctx, n, seeds, bin_w, bin_h, dout);
+    if (rc != RP_OK) return rc;
+    HIPCHK(ctx, hipMemcpy(item_wh_out, dout, (size_t)n * ctx->d.N * 2, hipMemcpyDeviceToHost));
+    return RP_OK;
+}
+
+extern "C" int rp_set_instance_pool_seeds(rp_ctx *ctx, int64_t n_instances, const uint32_t *seeds, int32_t bin_w, int32_t bin_h, uint64_t first_id) {
+    if (!ctx || n_instances < 0 || (n_instances > 0 && !seeds)) return fail(ctx, RP_ERR_ARG, "rp_set_instance_pool_seeds: bad argument");
+    DP &d = ctx->d;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_instances > ctx->pool_cap) {
+        ALLOC(ctx, ctx->pool_wh, (size_t)n_instances * d.N * 2);
+        ALLOC(ctx, ctx->pool_area, (size_t)n_instances);
+        ALLOC(ctx, ctx->pool_max_h, (size_t)n_instances);
+        ctx->pool_cap = n_instances;
+    }
+    if (n_instances > 0) {
+        int rc = generate_items_dev(ctx, n_instances, seeds, bin_w, bin_h, ctx->pool_wh);
+        if (rc != RP_OK) return rc;
+        // total area = the generator rectangle (CoachBPP.py:119); max_h over all items (BinPackingGame.py:41-50)
+        std::vector<u8> wh((size_t)n_instances * d.N * 2);
+        HIPCHK(ctx, hipMemcpy(wh.data(), ctx->pool_wh, wh.size(), hipMemcpyDeviceToHost));
+        std::vector<int> area((size_t)n_instances, bin_w * bin_h), mh((size_t)n_instances, 0);
+        for (int64_t k = 0; k < n_instances; ++k)
+            for (int i = 0; i < d.N; ++i) mh[k] = std::max(mh[k], (int)wh[((size_t)k * d.N + i) * 2 + 1]);
+        HIPCHK(ctx, hipMemcpy(ctx->pool_area, area.data(), area.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(ctx->pool_max_h, mh.data(), mh.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx, hipMemsetAsync(d.next_instance, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

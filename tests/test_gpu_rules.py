@@ -176,3 +176,31 @@ def test_masked_prior_matches_numpy(W, N):
         assert P.dtype == np.float64
         assert np.array_equal(got[b], P), (b, s)
     eng.close()
+
+
+def test_device_items_generator_matches_reference_golden_and_numpy():
+    """rp_generate_items (MT19937 + legacy randint on device) against ItemsGenerator.items_generator golden lists captured from
+    the reference, and against the package's NumPy generator on thousands of seeds (N = 128 needs more than one MT block)."""
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    d = json.load(open(os.path.join(GOLDEN, "items.json")))
+    groups = {}
+    for c in d["cases"]:
+        groups.setdefault((c["bin_w"], c["bin_h"], c["n"]), []).append(c)
+    n = 0
+    for (bw, bh, N), cases in groups.items():
+        eng = engine(bw, max(bw, bh), N)
+        got = eng.generate_items([c["seed"] for c in cases], bw, bh)
+        for k, c in enumerate(cases):
+            assert got[k].tolist() == [it[:2] for it in c["items"]], (bw, bh, N, c["seed"])
+            n += 1
+        eng.close()
+    assert n > 60
+    for (W, H, N, count) in [(20, 20, 32, 3000), (10, 10, 8, 2000), (50, 50, 128, 300), (64, 64, 128, 100)]:
+        eng = engine(W, H, N)
+        seeds = np.random.default_rng(W).integers(0, 100000, size=count)
+        got = eng.generate_items(seeds)
+        gen = ItemsGenerator(W, H, N)
+        for k in range(0, count, 7):
+            assert got[k].tolist() == [it[:2] for it in gen.items_generator(int(seeds[k]))], (W, N, seeds[k])
+        assert (got[:, :, 0].astype(int) * got[:, :, 1]).sum(axis=1).tolist() == [W * H] * count
+        eng.close()
