@@ -83,7 +83,7 @@ struct DP {  // device view of a context, passed by value to every kernel
     // level's chunk list; per slot a stack of recycled chunks and the count of never-used ones
     u16 *pa_cur, *pa_head, *pa_next, *pa_stack, *va_cur, *va_head, *va_next, *va_stack;
     u32 *pa_used, *pa_tf, *va_used, *va_tf;
-    u32 *peak_chunks;  // [2] high-water marks over all slots (sizing aid)
+    u32 *peak_chunks;  // [G][2] per-slot high-water marks (sizing aid)
     int *phase, *sims_done, *moves;
     u64 *episode;
     u32 *leaf_node;
@@ -94,7 +94,9 @@ struct DP {  // device view of a context, passed by value to every kernel
     double *last_score;
     double *last_v;     // value returned by the slot's latest simulation (MCTS.search's return value)
     int *last_vkind;
-    // evaluation queue
+    // evaluation rows: identity (row b = slot b, used by captured graphs: no atomics, fixed shapes) or the compact list that
+    // k_compact builds in slot order when the host asks for the number of waiting leaves
+    int rows_identity;
     int *eval_count, *eval_slot;
     // arenas
     NodeHdr *hdr;   // [G][node_cap]
@@ -114,7 +116,8 @@ struct DP {  // device view of a context, passed by value to every kernel
     // global
     double *g_bl;
     int *g_has_buf;
-    u64 *counters;
+    u64 *counters;   // [CNT_N] totals handed to the host (k_reduce_counters)
+    u64 *slot_cnt;   // [G][CNT_N] per-slot event counts: plain updates by the slot's own wave, no hot atomics
     int *error;
     // instance pool for auto_restart
     int auto_restart;
@@ -418,8 +421,9 @@ template <typename row_t> struct Tree {
     __device__ void store_sizes() {
         if (lane_id() == 0) {
             p.n_nodes[g] = n_nodes;
-            atomicMax(p.peak_chunks + 0, arena_in_use(pa));
-            atomicMax(p.peak_chunks + 1, arena_in_use(va));
+            u32 a = arena_in_use(pa), b = arena_in_use(va), *pk = p.peak_chunks + (size_t)g * 2;
+            if (a > pk[0]) pk[0] = a;
+            if (b > pk[1]) pk[1] = b;
         }
     }
     __device__ void reset_arenas() { arena_reset(pa, p.N + 1); arena_reset(va, p.N + 1); }
@@ -641,10 +645,12 @@ template <typename row_t> struct Tree {
     }
 };
 
-template <typename T> __device__ void add_counters(const DP &p, const T *c) {
-    if (lane_id() == 0)
+template <typename T> __device__ void add_counters(const DP &p, int g, const T *c) {
+    if (lane_id() == 0) {
+        u64 *dst = p.slot_cnt + (size_t)g * CNT_N;
         for (int k = 0; k < CNT_N; ++k)
-            if (c[k]) atomicAdd(p.counters + k, (u64)c[k]);
+            if (c[k]) dst[k] += (u64)c[k];
+    }
 }
 
 __device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(mix64(seed) ^ episode) ^ move); }
@@ -887,9 +893,6 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
             if (lane == 0) {
                 p.leaf_node[g] = node;
                 p.path_len[g] = depth;
-                int b = atomicAdd(p.eval_count, 1);
-                p.eval_slot[b] = g;
-                p.game_row[g] = b;
             }
             phase = RP_PHASE_WAIT_EVAL;
             break;
@@ -905,7 +908,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
     t.store_sizes();
     c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
     if (lane == 0) { p.phase[g] = phase; p.sims_done[g] = sims_done; }
-    add_counters(p, c);
+    add_counters(p, g, c);
 }
 
 // CoachBPP.executeEpisode's move for every slot whose search budget is spent (RP_MOVE_ARGMAX_FIRST / RP_MOVE_SAMPLE), and the
@@ -928,7 +931,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
     }
     t.store_sizes();
     c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
-    add_counters(p, c);
+    add_counters(p, g, c);
 }
 
 // np.sum(Ps[s]) over the dense A-vector in NumPy's pairwise order (MCTS_bpp.py:90,100).  mode 0:
@@ -1002,8 +1005,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
     __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id(), wv = threadIdx.x >> 6;
-    if (b >= *p.eval_count) return;
-    const int g = p.eval_slot[b];
+    if (b >= (p.rows_identity ? p.G : *p.eval_count)) return;
+    const int g = p.rows_identity ? b : p.eval_slot[b];
+    if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     const u32 node = p.leaf_node[g];
     NodeHdr hd = t.hdr[node];
@@ -1019,8 +1023,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     for (int d = lane; d < depth; d += 64) t.backup_entry(pn[d], pe[d], v, RP_KIND_F32);
     if (lane == 0) {
         p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32;
-        atomicAdd(p.counters + CNT_SIMS, 1ull); atomicAdd(p.counters + CNT_EXPAND, 1ull);
-        atomicAdd(p.counters + CNT_NVALID_LEAF, (u64)hd.n_valid);
+        u64 *cn = p.slot_cnt + (size_t)g * CNT_N;
+        cn[CNT_SIMS] += 1; cn[CNT_EXPAND] += 1; cn[CNT_NVALID_LEAF] += hd.n_valid;
     }
 }
 
@@ -1048,8 +1052,9 @@ __device__ void write_planes(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_planes(DP p, float *planes, long long capacity_rows) {
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (b >= *p.eval_count || b >= capacity_rows) return;
-    const int g = p.eval_slot[b];
+    if (b >= (p.rows_identity ? p.G : *p.eval_count) || b >= capacity_rows) return;
+    const int g = p.rows_identity ? b : p.eval_slot[b];
+    if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     row_t myrow; u64 rem0, rem1;
     t.load_key(p.leaf_node[g], myrow, rem0, rem1);
@@ -1097,94 +1102,108 @@ __global__ void k_stem_tables(int N, const float *w /*[16][N+1][3][3]*/, const f
     }
 }
 
-template <typename row_t>
+// T_LDS: the item table (N * 25 * 16 floats, 51 KB at N = 32) is staged in LDS once per workgroup and the workgroup's waves
+// loop over leaves -- the table rows a wave touches differ from lane to lane, which made the L1/L2 round trip of every
+// 64-byte row the kernel's critical path.  Larger tables (N > 40) stay in L2.
+template <typename row_t, bool T_LDS>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows) {
-    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
-    if (b >= *p.eval_count || b >= capacity_rows) return;
-    const int g = p.eval_slot[b];
-    Tree<row_t> t(p, g);
-    row_t myrow; u64 rem0, rem1;
-    t.load_key(p.leaf_node[g], myrow, rem0, rem1);
-    // item sizes live in lanes (item i in lane i & 63), broadcast with readlane inside the uniform item loop: no memory traffic
-    int wh_lo = 0, wh_hi = 0;
-    if (lane < p.N) wh_lo = t.wh[2 * lane] | (t.wh[2 * lane + 1] << 8);
-    if (lane + 64 < p.N) wh_hi = t.wh[2 * (lane + 64)] | (t.wh[2 * (lane + 64) + 1] << 8);
+    extern __shared__ __attribute__((aligned(16))) float4 sT4[];
+    const int lane = lane_id();
+    if (T_LDS) {
+        const int n4 = p.N * 25 * STEM_C / 4;
+        const float4 *src = (const float4 *)p.stemT;
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) sT4[i] = src[i];
+        __syncthreads();
+    }
+    const long long rows = p.rows_identity ? (long long)p.G : (long long)*p.eval_count;
+    const long long limit = rows < capacity_rows ? rows : capacity_rows;
     const int P = p.Hp * p.Wp;
-    float *ob = out + (size_t)b * STEM_C * P;
     float bias[STEM_C];
 #pragma unroll
     for (int o = 0; o < STEM_C; ++o) bias[o] = p.stemBias[o];
-    for (int base = 0; base < P; base += 64) {
-        const int pp = base + lane;
-        const bool live = pp < P;
-        const int pr = live ? pp / p.Wp : 0, px = live ? pp - (pp / p.Wp) * p.Wp : 0;
-        row_t rw[5];  // grid rows 2pr-2 .. 2pr+2 (zero outside the grid); shuffles need every lane
+    for (long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); b < limit; b += (long long)gridDim.x * WAVES_PER_BLOCK) {
+        const int g = p.rows_identity ? (int)b : p.eval_slot[b];
+        if (p.phase[g] != RP_PHASE_WAIT_EVAL) continue;
+        Tree<row_t> t(p, g);
+        row_t myrow; u64 rem0, rem1;
+        t.load_key(p.leaf_node[g], myrow, rem0, rem1);
+        // item sizes live in lanes (item i in lane i & 63), broadcast with readlane inside the uniform item loop: no memory traffic
+        int wh_lo = 0, wh_hi = 0;
+        if (lane < p.N) wh_lo = t.wh[2 * lane] | (t.wh[2 * lane + 1] << 8);
+        if (lane + 64 < p.N) wh_hi = t.wh[2 * (lane + 64)] | (t.wh[2 * (lane + 64) + 1] << 8);
+        float *ob = out + (size_t)b * STEM_C * P;
+        for (int base = 0; base < P; base += 64) {
+            const int pp = base + lane;
+            const bool live = pp < P;
+            const int pr = live ? pp / p.Wp : 0, px = live ? pp - (pp / p.Wp) * p.Wp : 0;
+            row_t rw[5];  // grid rows 2pr-2 .. 2pr+2 (zero outside the grid); shuffles need every lane
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            int rr = 2 * pr - 2 + q;
-            row_t v = __shfl(myrow, rr & 63);
-            rw[q] = (rr >= 0 && rr < p.H) ? v : (row_t)0;
-        }
-        float best[STEM_C];
-#pragma unroll
-        for (int o = 0; o < STEM_C; ++o) best[o] = -INFINITY;
-        for (int wr = 0; wr < 3; ++wr) {  // one row of the pooling window at a time: three convolution outputs per lane
-            const int r = 2 * pr - 1 + wr;
-            const bool rowok = live && r >= 0 && r < p.H;
-            float acc[3][STEM_C];
-#pragma unroll
-            for (int wx = 0; wx < 3; ++wx)
-#pragma unroll
-                for (int o = 0; o < STEM_C; ++o) acc[wx][o] = bias[o];
-            const row_t r0 = wr == 0 ? rw[0] : (wr == 1 ? rw[1] : rw[2]), r1 = wr == 0 ? rw[1] : (wr == 1 ? rw[2] : rw[3]),
-                        r2 = wr == 0 ? rw[2] : (wr == 1 ? rw[3] : rw[4]);
-#pragma unroll
-            for (int wx = 0; wx < 3; ++wx) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
-                const int x = 2 * px - 1 + wx;
-                if (!(rowok && x >= 0 && x < p.W)) continue;
-                u32 b0 = x ? (u32)((r0 >> (x - 1)) & 7) : (u32)((r0 << 1) & 7);
-                u32 b1 = x ? (u32)((r1 >> (x - 1)) & 7) : (u32)((r1 << 1) & 7);
-                u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
-                u32 pat = b0 | (b1 << 3) | (b2 << 6);
-                if (pat) {
-                    const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
-                }
+            for (int q = 0; q < 5; ++q) {
+                int rr = 2 * pr - 2 + q;
+                row_t v = __shfl(myrow, rr & 63);
+                rw[q] = (rr >= 0 && rr < p.H) ? v : (row_t)0;
             }
-            for (int i = 0; i < p.N; ++i) {
-                if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
-                const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
-                const int iw = whi & 255, ih = whi >> 8;
-                const int rc = rowok ? stem_class(r, ih) : -1;
-                if (__ballot(rc >= 0) == 0ull) continue;  // no lane's row touches this item
-                if (rc < 0) continue;
-                const float *trow = p.stemT + (size_t)(i * 5 + rc) * 5 * STEM_C;
+            float best[STEM_C];
+#pragma unroll
+            for (int o = 0; o < STEM_C; ++o) best[o] = -INFINITY;
+            for (int wr = 0; wr < 3; ++wr) {  // one row of the pooling window at a time: three convolution outputs per lane
+                const int r = 2 * pr - 1 + wr;
+                const bool rowok = live && r >= 0 && r < p.H;
+                float acc[3][STEM_C];
+#pragma unroll
+                for (int wx = 0; wx < 3; ++wx)
+#pragma unroll
+                    for (int o = 0; o < STEM_C; ++o) acc[wx][o] = bias[o];
+                const row_t r0 = wr == 0 ? rw[0] : (wr == 1 ? rw[1] : rw[2]), r1 = wr == 0 ? rw[1] : (wr == 1 ? rw[2] : rw[3]),
+                            r2 = wr == 0 ? rw[2] : (wr == 1 ? rw[3] : rw[4]);
+#pragma unroll
+                for (int wx = 0; wx < 3; ++wx) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
+                    const int x = 2 * px - 1 + wx;
+                    if (!(rowok && x >= 0 && x < p.W)) continue;
+                    u32 b0 = x ? (u32)((r0 >> (x - 1)) & 7) : (u32)((r0 << 1) & 7);
+                    u32 b1 = x ? (u32)((r1 >> (x - 1)) & 7) : (u32)((r1 << 1) & 7);
+                    u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
+                    u32 pat = b0 | (b1 << 3) | (b2 << 6);
+                    if (pat) {
+                        const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
+                    }
+                }
+                for (int i = 0; i < p.N; ++i) {
+                    if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
+                    const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
+                    const int iw = whi & 255, ih = whi >> 8;
+                    const int rc = rowok ? stem_class(r, ih) : -1;
+                    if (__ballot(rc >= 0) == 0ull) continue;  // no lane's row touches this item
+                    if (rc < 0) continue;
+                    const int trow = (i * 5 + rc) * 5;
+#pragma unroll
+                    for (int wx = 0; wx < 3; ++wx) {
+                        const int x = 2 * px - 1 + wx;
+                        const int cc = (x >= 0 && x < p.W) ? stem_class(x, iw) : -1;
+                        if (cc < 0) continue;
+                        const float4 *tt = T_LDS ? (sT4 + (trow + cc) * (STEM_C / 4)) : ((const float4 *)p.stemT + (size_t)(trow + cc) * (STEM_C / 4));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
+                    }
+                }
 #pragma unroll
                 for (int wx = 0; wx < 3; ++wx) {
                     const int x = 2 * px - 1 + wx;
-                    const int cc = (x >= 0 && x < p.W) ? stem_class(x, iw) : -1;
-                    if (cc < 0) continue;
-                    const float4 *tt = (const float4 *)(trow + cc * STEM_C);
+                    if (!(rowok && x >= 0 && x < p.W)) continue;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
+                    for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[wx][o]);
                 }
             }
+            if (live) {
 #pragma unroll
-            for (int wx = 0; wx < 3; ++wx) {
-                const int x = 2 * px - 1 + wx;
-                if (!(rowok && x >= 0 && x < p.W)) continue;
+                for (int o = 0; o < STEM_C; ++o) ob[(size_t)o * P + pp] = best[o];
+                if (out_relu) {
+                    float *orl = out_relu + (size_t)b * STEM_C * P;
 #pragma unroll
-                for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[wx][o]);
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int o = 0; o < STEM_C; ++o) ob[(size_t)o * P + pp] = best[o];
-            if (out_relu) {
-                float *orl = out_relu + (size_t)b * STEM_C * P;
-#pragma unroll
-                for (int o = 0; o < STEM_C; ++o) orl[(size_t)o * P + pp] = best[o] > 0.f ? best[o] : 0.f;
+                    for (int o = 0; o < STEM_C; ++o) orl[(size_t)o * P + pp] = best[o] > 0.f ? best[o] : 0.f;
+                }
             }
         }
     }
@@ -1195,6 +1214,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_states(DP p, u64 
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (b >= *p.eval_count || b >= max_rows) return;
     const int g = p.eval_slot[b];
+    if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     row_t myrow; u64 rem0, rem1;
     t.load_key(p.leaf_node[g], myrow, rem0, rem1);
@@ -1243,7 +1263,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, c);
+    add_counters(p, g, c);
     if (lane == 0) {
         p.root[g] = id;
         p.sims_done[g] = 0;
@@ -1265,7 +1285,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     play_move_impl<row_t>(p, t, g, root, action[k], c);
     t.store_sizes();
     c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, c);
+    add_counters(p, g, c);
 }
 
 // counts[a] = Nsa[(root, a)] (MCTS_bpp.py:40-41)
@@ -1295,7 +1315,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     restart_slot_impl<row_t>(p, t, g, root, c);
     t.store_sizes();
     c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, c);
+    add_counters(p, g, c);
 }
 
 // Training tensors of recorded examples: planes as getBinItem (BinPackingGame.py:118-120), pi = counts / sum in
@@ -1396,6 +1416,46 @@ __global__ void k_items_generator(long long n, int N, int bin_w, int bin_h, cons
     }
     u8 *o = out_wh + (size_t)t * N * 2;
     for (int i = 0; i < N; ++i) { o[2 * i] = L[i][0]; o[2 * i + 1] = L[i][1]; }
+}
+
+// Compact list of the slots that wait for the evaluator, in slot order (deterministic).  One workgroup.
+__global__ void __launch_bounds__(1024) k_compact(DP p) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, wid = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < p.G; start += 1024) {
+        int g = start + tid;
+        bool flag = g < p.G && p.phase[g] == RP_PHASE_WAIT_EVAL;
+        u64 m = __ballot(flag);
+        if ((tid & 63) == 0) wsum[wid] = __popcll(m);
+        __syncthreads();
+        int off = base + __popcll(m & lanes_below());
+        for (int w = 0; w < wid; ++w) off += wsum[w];
+        if (flag) { p.eval_slot[off] = g; p.game_row[g] = off; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *p.eval_count = base;
+}
+__global__ void k_reduce_counters(DP p) {  // totals over slots; one workgroup, thread k sums counter k % CNT_N over a slot stripe
+    __shared__ u64 part[1024];
+    const int tid = threadIdx.x, k = tid % CNT_N, stripe = tid / CNT_N, n_str = 1024 / CNT_N;
+    u64 acc = 0;
+    for (int g = stripe; g < p.G; g += n_str) acc += p.slot_cnt[(size_t)g * CNT_N + k];
+    part[tid] = acc;
+    __syncthreads();
+    if (tid < CNT_N) { u64 t = 0; for (int s2 = 0; s2 < n_str; ++s2) t += part[s2 * CNT_N + tid]; p.counters[tid] = t; }
+}
+__global__ void k_reduce_peaks(DP p, u32 *out2) {
+    __shared__ u32 m0[256], m1[256];
+    u32 a = 0, b = 0;
+    for (int g = threadIdx.x; g < p.G; g += 256) { a = max(a, p.peak_chunks[(size_t)g * 2]); b = max(b, p.peak_chunks[(size_t)g * 2 + 1]); }
+    m0[threadIdx.x] = a; m1[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int i = 1; i < 256; ++i) { a = max(a, m0[i]); b = max(b, m1[i]); } out2[0] = a; out2[1] = b; }
 }
 
 // ---- stateless rule kernels (one wave per state) ----
@@ -1681,6 +1741,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.edge_cap = d.n_pchunks * d.pchunk;
     d.vis_cap = d.n_vchunks * d.vchunk;
     d.reclaim = cfg->reclaim ? 1 : 0;
+    d.rows_identity = 0;
     int tc = 64;
     while (tc < 2 * d.node_cap) tc *= 2;
     d.table_cap = tc;
@@ -1707,8 +1768,8 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.table, G * d.table_cap);
     A_(d.pa_cur, G * (N + 1)); A_(d.pa_head, G * (N + 1)); A_(d.pa_used, G * (N + 1)); A_(d.pa_next, G * d.n_pchunks); A_(d.pa_stack, G * d.n_pchunks); A_(d.pa_tf, G * 2);
     A_(d.va_cur, G * (N + 1)); A_(d.va_head, G * (N + 1)); A_(d.va_used, G * (N + 1)); A_(d.va_next, G * d.n_vchunks); A_(d.va_stack, G * d.n_vchunks); A_(d.va_tf, G * 2);
-    A_(d.peak_chunks, 2);
-    A_(d.g_bl, 1); A_(d.g_has_buf, 1); A_(d.counters, CNT_N); A_(d.error, 1);
+    A_(d.peak_chunks, G * 2 + 2);
+    A_(d.g_bl, 1); A_(d.g_has_buf, 1); A_(d.counters, CNT_N); A_(d.slot_cnt, G * CNT_N); A_(d.error, 1);
     d.fin_cap = (int)std::max<size_t>(4 * G, 1024);
     A_(d.fin_count, 1); A_(d.fin_episode, d.fin_cap); A_(d.fin_outcome, d.fin_cap); A_(d.fin_moves, d.fin_cap); A_(d.fin_score, d.fin_cap);
     d.auto_restart = cfg->auto_restart; d.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
@@ -1928,11 +1989,15 @@ extern "C" int rp_last_values(rp_ctx *ctx, int32_t first, int32_t count, double 
 
 extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
     if (!ctx) return RP_ERR_ARG;
-    const DP &d = ctx->d;
-    HIPCHK(ctx, hipMemsetAsync(d.eval_count, 0, sizeof(int), ctx->stream));
+    DP &d = ctx->d;
     if (d.move_rule != RP_MOVE_EXTERNAL) DISPATCH(ctx, k_moves, grid_for(d.G), d);
     DISPATCH(ctx, k_search, grid_for(d.G), d);
+    // Without a count request nothing is synchronised and evaluator row b belongs to slot b (fixed shapes for graph capture);
+    // with one, the waiting slots are listed in slot order and rows follow that list.
+    d.rows_identity = n_leaves_out ? 0 : 1;
     if (n_leaves_out) {
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, d);
+        HIPCHK(ctx, hipGetLastError());
         int n = 0;
         HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         int rc = check_device_error(ctx);  // synchronises
@@ -1971,7 +2036,17 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     if (!d.stemT) return fail(ctx, RP_ERR_STATE, "rp_leaf_stem: call rp_stem_set_weights first");
     long long rows = std::min<long long>(capacity_rows, d.G);
     if (rows == 0) return RP_OK;
-    DISPATCH(ctx, k_leaf_stem, grid_for(rows), d, out_dev, out_relu_dev, (long long)capacity_rows);
+    const size_t t_bytes = (size_t)d.N * 25 * STEM_C * sizeof(float);
+    const bool t_lds = t_bytes <= 64 * 1024;
+    const int grid = (int)std::min<long long>(grid_for(rows), t_lds ? 256 * 3 : 1 << 20);  // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32)
+    if (ctx->row64) {
+        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+        else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+    } else {
+        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u32, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+        else hipLaunchKernelGGL((k_leaf_stem<u32, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+    }
+    HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }
 
@@ -2012,6 +2087,7 @@ extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bia
 extern "C" int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out, uint8_t *remaining_out, int32_t *slot_out, int32_t *n_out) {
     if (!ctx || max_rows < 0 || !rows_out || !remaining_out || !slot_out || !n_out) return fail(ctx, RP_ERR_ARG, "rp_leaf_states: bad argument");
     const DP &d = ctx->d;
+    if (d.rows_identity) return fail(ctx, RP_ERR_STATE, "rp_leaf_states: call rp_search_step with n_leaves_out first (compact rows)");
     int n = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2040,6 +2116,7 @@ extern "C" int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_d
 extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows) {
     if (!ctx || !pi_host || !v_host || n_rows < 0) return fail(ctx, RP_ERR_ARG, "rp_commit_eval_host: bad argument");
     const DP &d = ctx->d;
+    if (d.rows_identity) return fail(ctx, RP_ERR_STATE, "rp_commit_eval_host: call rp_search_step with n_leaves_out first (compact rows)");
     int n = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2236,8 +2313,10 @@ extern "C" int rp_examples_clear(rp_ctx *ctx) {
 
 extern "C" int rp_counters(rp_ctx *ctx, int64_t *out16, int32_t reset) {
     if (!ctx || !out16) return fail(ctx, RP_ERR_ARG, "rp_counters: bad argument");
+    hipLaunchKernelGGL(k_reduce_counters, dim3(1), dim3(1024), 0, ctx->stream, ctx->d);
+    HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out16, ctx->d.counters, CNT_N * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d.counters, 0, CNT_N * sizeof(u64), ctx->stream));
+    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d.slot_cnt, 0, (size_t)ctx->d.G * CNT_N * sizeof(u64), ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RP_OK;
 }
@@ -2253,7 +2332,10 @@ extern "C" int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int
 extern "C" int rp_arena_peak(rp_ctx *ctx, int32_t *prior_chunks_out, int32_t *visited_chunks_out, int32_t *chunk_entries_out2) {
     if (!ctx || !prior_chunks_out || !visited_chunks_out) return fail(ctx, RP_ERR_ARG, "rp_arena_peak: bad argument");
     u32 pk[2] = {0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(pk, ctx->d.peak_chunks, sizeof pk, hipMemcpyDeviceToHost, ctx->stream));
+    u32 *tail = ctx->d.peak_chunks + (size_t)ctx->d.G * 2;
+    hipLaunchKernelGGL(k_reduce_peaks, dim3(1), dim3(256), 0, ctx->stream, ctx->d, tail);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(pk, tail, sizeof pk, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *prior_chunks_out = (int)pk[0]; *visited_chunks_out = (int)pk[1];
     if (chunk_entries_out2) { chunk_entries_out2[0] = ctx->d.pchunk; chunk_entries_out2[1] = ctx->d.vchunk; }
