@@ -587,38 +587,42 @@ template <typename row_t> struct Tree {
     // move index.  Visited edges come from the node's block (Q + cpuct*P*sqrt(Ns)/(1+Nsa)), all others from the prior run
     // (cpuct*P*sqrt(Ns+EPS)); an LDS bit mask tells the two apart.  Returns the visited-entry index of the chosen edge
     // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.
-    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out) {
+    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out, u32 &child_out) {
         const int lane = lane_id();
         const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
         const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
-        const u32 words = ((u32)hd.n_valid + 31u) >> 5;
-        for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
-        wave_sync();
         double best_u = -INFINITY;
-        u32 best_k = NONE32, best_e = NONE32;
-        for (u32 j = lane; j < hd.vis_n; j += 64) {
-            u32 e = hd.vis_off + j, k = vIdx[e];
-            atomicOr(&vmask[k >> 5], 1u << (k & 31));
-            u32 nn = vN[e] & NSA_MASK;
-            double cp = p.cpuct * vP[e];
-            double u = nn ? vQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
-            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; }
+        u32 best_k = NONE32, best_e = NONE32, best_c = NONE32;
+        const bool any_visited = hd.vis_n != 0;
+        if (any_visited) {
+            const u32 words = ((u32)hd.n_valid + 31u) >> 5;
+            for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
+            wave_sync();
+            for (u32 j = lane; j < hd.vis_n; j += 64) {
+                u32 e = hd.vis_off + j, k = vIdx[e];
+                atomicOr(&vmask[k >> 5], 1u << (k & 31));
+                u32 nn = vN[e] & NSA_MASK, ch = vChild[e];  // the child link rides along: no extra round trip after the argmax
+                double cp = p.cpuct * vP[e];
+                double u = nn ? vQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
+                if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; }
+            }
+            wave_sync();
         }
-        wave_sync();
         const bool fb = (hd.flags & HF_FALLBACK) != 0;
         for (u32 k = lane; k < hd.n_valid; k += 64) {
-            if ((vmask[k >> 5] >> (k & 31)) & 1u) continue;
+            if (any_visited && ((vmask[k >> 5] >> (k & 31)) & 1u)) continue;
             double u = (p.cpuct * prior_of(pPi[hd.prior_off + k], hd.norm, fb)) * s_new;
-            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = NONE32; }
+            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = NONE32; best_c = NONE32; }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             double ou = __shfl_xor(best_u, o);
-            u32 ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o);
-            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; }
+            u32 ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o), oc = __shfl_xor(best_c, o);
+            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; best_c = oc; }
         }
-        wave_sync();
+        if (any_visited) wave_sync();  // the mask is reused by the next selection
         k_out = best_k;
+        child_out = best_c;
         if (best_k == NONE32) return NONE32;
         if (best_e == NONE32) best_e = append_visited(node, hd, best_k);
         return best_e;
@@ -827,7 +831,7 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
 // MCTS.search (MCTS_bpp.py:56-139) for all slots: each wave runs simulations of its game until one
 // needs the evaluator or the move's budget is spent.
 template <typename row_t>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) k_search(DP p) {
     __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     u32 *vmask = s_vmask[threadIdx.x >> 6];
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
@@ -861,17 +865,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_search(DP p) {
                 break;
             }
             if (!(hd.flags & HF_EXPANDED)) { need_eval = true; break; }  // :85 leaf
-            u32 ksel;
+            u32 ksel, child;
             const u32 vis_before = hd.vis_n;
-            u32 e = t.select_edge(node, hd, vmask, ksel);
+            u32 e = t.select_edge(node, hd, vmask, ksel, child);
             c[CNT_VIS_NEW] += hd.vis_n - vis_before;
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
             if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
             else if (lane == depth - 64) { pe1 = e; pn1 = node; }
             depth++;
             c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid; c[CNT_VIS_SEL] += vis_before;
-            wave_sync();
-            u32 child = t.vChild[e];
             if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
                 bool was_new;
                 child = t.resolve_child(node, e, t.pAct[hd.prior_off + ksel], &was_new);
