@@ -170,18 +170,20 @@ int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows);
  * rp_leaf_stem writes FP32 [n][16][(H+1)/2][(W+1)/2] into caller-owned DEVICE memory, the input of conv_seqs[0].res_block0.
  * Same result as rp_leaf_planes + the two PyTorch ops up to float32 summation order. */
 int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const float *bias_dev);
-int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), may be NULL */, int64_t capacity_rows);
+int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), may be NULL */, int64_t capacity_rows,
+                 int32_t channels_last /* 0: [n][16][Hp][Wp], 1: [n][Hp][Wp][16] (MIOpen's FP32 kernels are faster on NHWC) */);
 /* Fused element-wise pieces of the evaluator on the context's stream (NCHW float32 DEVICE tensors).  PyTorch-ROCm runs the
  * bias add of a convolution, each ReLU, the residual add and the max-pool of BinpackingNNet.py:21-27,39-40 as separate
  * HBM-bound kernels; these apply the same operations in the same order in one pass:
  *   rp_nn_bias_relu      x = relu(x + bias[c])                                       (in place)
  *   rp_nn_bias_residual  out = (x + bias[c]) + res ; out_relu = relu(out)            (out_relu may be NULL)
- *   rp_nn_bias_pool      out = max_pool2d(x + bias[c], 3, stride 2, pad 1) ; out_relu = relu(out) */
+ *   rp_nn_bias_pool      out = max_pool2d(x + bias[c], 3, stride 2, pad 1) ; out_relu = relu(out)
+ * Channels-last tensors: call the first two with (B*H*W, C, 1), the pool with channels_last = 1. */
 int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
                         int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bias_dev, float *out_dev, float *out_relu_dev, int64_t B, int32_t C, int32_t H,
-                    int32_t W);
+                    int32_t W, int32_t channels_last);
 /* Host copy of the waiting leaves' packed states and slots (parity tests, host evaluators). */
 int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out /*[n][H]*/, uint8_t *remaining_out /*[n][N]*/,
                    int32_t *slot_out /*[n]*/, int32_t *n_out);

@@ -62,10 +62,10 @@ _SIGS = {
     "rp_search_step": (C.c_int, [_vp, _vp]),
     "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
     "rp_stem_set_weights": (C.c_int, [_vp, _vp, _vp]),
-    "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64, _i32]),
     "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
-    "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
+    "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32]),
     "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "rp_commit_eval": (C.c_int, [_vp, _vp, _vp]),
     "rp_commit_eval_host": (C.c_int, [_vp, _vp, _vp, _i32]),
@@ -260,25 +260,39 @@ class Engine:
     def stem_set_weights(self, conv_w_dev_ptr, bias_dev_ptr):
         self._ck(self.L.rp_stem_set_weights(self.h, C.c_void_p(conv_w_dev_ptr), C.c_void_p(bias_dev_ptr)))
 
-    def leaf_stem(self, dev_ptr, capacity_rows, relu_dev_ptr=None):
-        self._ck(self.L.rp_leaf_stem(self.h, C.c_void_p(dev_ptr), C.c_void_p(relu_dev_ptr) if relu_dev_ptr else None, capacity_rows))
+    def leaf_stem(self, dev_ptr, capacity_rows, relu_dev_ptr=None, channels_last=False):
+        self._ck(self.L.rp_leaf_stem(self.h, C.c_void_p(dev_ptr), C.c_void_p(relu_dev_ptr) if relu_dev_ptr else None, capacity_rows,
+                                     1 if channels_last else 0))
 
-    # fused element-wise evaluator pieces on torch tensors (contiguous float32 NCHW on this context's device)
+    # fused element-wise evaluator pieces on torch tensors (float32 on this context's device, NCHW-contiguous or channels-last)
+    @staticmethod
+    def _bchw(x):
+        """(rows, channels, inner) such that element e has channel (e // inner) % channels in x's memory order."""
+        if x.dim() == 4 and not x.is_contiguous():
+            import torch
+            if not x.is_contiguous(memory_format=torch.channels_last):
+                raise ValueError("tensor must be contiguous or channels-last")
+            return x.shape[0] * x.shape[2] * x.shape[3], x.shape[1], 1
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.shape[0], x.shape[1], x[0, 0].numel()
+
     def nn_bias_relu(self, x, bias):
-        B, Cc = x.shape[0], x.shape[1]
-        self._ck(self.L.rp_nn_bias_relu(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), B, Cc, x[0, 0].numel()))
+        B, Cc, inner = self._bchw(x)
+        self._ck(self.L.rp_nn_bias_relu(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), B, Cc, inner))
         return x
 
     def nn_bias_residual(self, x, bias, res, out, out_relu=None):
-        B, Cc = x.shape[0], x.shape[1]
+        B, Cc, inner = self._bchw(x)
         self._ck(self.L.rp_nn_bias_residual(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(res.data_ptr()),
                                             C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None,
-                                            B, Cc, x[0, 0].numel()))
+                                            B, Cc, inner))
 
     def nn_bias_pool(self, x, bias, out, out_relu=None):
         B, Cc, H, W = x.shape
+        cl = self._bchw(x)[2] == 1 and H * W > 1
         self._ck(self.L.rp_nn_bias_pool(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
-                                        C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, Cc, H, W))
+                                        C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, Cc, H, W, 1 if cl else 0))
 
     def leaf_states(self, max_rows=None):
         max_rows = self.G if max_rows is None else max_rows

@@ -87,49 +87,65 @@ class BinPackingNNet(nn.Module):
     # On a 3x3 (or smaller) image a padded 3x3 convolution is a dense (C*h*w) x (C*h*w) matrix; MIOpen still pays a full
     # Winograd launch for it.  The matrices are read off the convolution itself (its response to the identity batch, so every
     # entry is exactly one weight) and refreshed in place after weight updates, which keeps captured HIP graphs valid.
+    # Both memory orders are kept: NCHW-flattened (c, h, w) and channels-last-flattened (h, w, c).
     DENSE_MAX_PIXELS = 9
 
-    def _dense_key(self, si, which):
-        return "%d:%s" % (si, which)
+    def _set_cached(self, key, value):
+        if not hasattr(self, "_dense"):
+            self._dense = {}
+        if key in self._dense and self._dense[key].shape == value.shape:
+            self._dense[key].copy_(value)
+        else:
+            self._dense[key] = value.contiguous()
 
     def refresh_dense(self):
         shapes = stage_shapes(self.in_channels, self.board_h, self.board_w)
-        if not hasattr(self, "_dense"):
-            self._dense = {}
         with torch.no_grad():
             for si, stage in enumerate(self.conv_seqs):
                 ch, h, w = shapes[si]
                 if h * w > self.DENSE_MAX_PIXELS:
                     continue
+                n = ch * h * w
                 for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
                     for ci, conv in enumerate((blk.conv0, blk.conv1)):
-                        eye = torch.eye(ch * h * w, device=conv.weight.device, dtype=conv.weight.dtype).view(-1, ch, h, w)
-                        mt = F.conv2d(eye, conv.weight, None, padding=1).flatten(1).contiguous()
-                        key = self._dense_key(si, "b%dc%d" % (bi, ci))
-                        if key in self._dense:
-                            self._dense[key].copy_(mt)
-                        else:
-                            self._dense[key] = mt
+                        eye = torch.eye(n, device=conv.weight.device, dtype=conv.weight.dtype)
+                        key = "%d:b%dc%d" % (si, bi, ci)
+                        self._set_cached(key, F.conv2d(eye.view(n, ch, h, w), conv.weight, None, padding=1).flatten(1))
+                        resp = F.conv2d(eye.view(n, h, w, ch).permute(0, 3, 1, 2), conv.weight, None, padding=1)
+                        self._set_cached(key + ":cl", resp.permute(0, 2, 3, 1).reshape(n, n))
+            ch, h, w = shapes[-1]  # hidden_fc on channels-last features: columns reordered from (c, h, w) to (h, w, c)
+            self._set_cached("hidden:cl", self.hidden_fc.weight.view(-1, ch, h, w).permute(0, 2, 3, 1).reshape(self.hidden_fc.out_features, -1))
         return self._dense
 
+    @staticmethod
+    def _is_cl(x):
+        return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
     def _conv_nobias(self, x, conv, si, which):
-        mt = getattr(self, "_dense", {}).get(self._dense_key(si, which))
+        cl = self._is_cl(x)
+        mt = getattr(self, "_dense", {}).get("%d:%s%s" % (si, which, ":cl" if cl else ""))
         if mt is None:
             return F.conv2d(x, conv.weight, None, padding=1)
-        return torch.mm(x.flatten(1), mt).view(x.shape[0], conv.out_channels, x.shape[2], x.shape[3])
+        b, _, h, w = x.shape
+        if cl:
+            return torch.mm(x.permute(0, 2, 3, 1).reshape(b, -1), mt).view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
+        return torch.mm(x.flatten(1), mt).view(b, conv.out_channels, h, w)
 
     def forward_from_stem_fused(self, y, y_relu, ops):
         """Same network as forward_from_stem with the element-wise work fused: convolutions run without bias through
         PyTorch-ROCm, and `ops` (an engine: rp_nn_bias_relu / rp_nn_bias_residual / rp_nn_bias_pool) applies bias + ReLU,
         bias + skip (+ the next block's ReLU) and bias + max-pool in one pass each -- 4 kernels per residual block
         instead of 7, the same float32 operations in the same order.  Convolutions on <= 3x3 images run as one GEMM each
-        when refresh_dense() has been called.  y_relu = relu(y).  Returns (softmax, tanh)."""
+        when refresh_dense() has been called.  Works on NCHW-contiguous or channels-last tensors (MIOpen's FP32 kernels
+        are 20-30 % faster on the latter).  y_relu = relu(y).  Returns (softmax, tanh)."""
+        cl = self._is_cl(y)
+        fmt = torch.channels_last if cl else torch.contiguous_format
         x, xr = y, y_relu
         for si, stage in enumerate(self.conv_seqs):
             if si > 0:
                 c = F.conv2d(x, stage.conv.weight, None, padding=1)
                 b, ch, h, w = c.shape
-                x = c.new_empty((b, ch, (h + 1) // 2, (w + 1) // 2))
+                x = torch.empty((b, ch, (h + 1) // 2, (w + 1) // 2), device=c.device, dtype=c.dtype, memory_format=fmt)
                 xr = torch.empty_like(x)
                 ops.nn_bias_pool(c, stage.conv.bias, x, xr)
             for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
@@ -139,7 +155,11 @@ class BinPackingNNet(nn.Module):
                 out, out_r = torch.empty_like(c1), torch.empty_like(c1)
                 ops.nn_bias_residual(c1, blk.conv1.bias, x, out, out_r)
                 x, xr = out, out_r
-        z = F.linear(torch.flatten(xr, start_dim=1), self.hidden_fc.weight, None)
+        hw = getattr(self, "_dense", {}).get("hidden:cl") if cl else None
+        if cl and hw is not None:
+            z = F.linear(xr.permute(0, 2, 3, 1).reshape(xr.shape[0], -1), hw, None)
+        else:
+            z = F.linear(torch.flatten(xr, start_dim=1), self.hidden_fc.weight, None)
         ops.nn_bias_relu(z.view(z.shape[0], z.shape[1], 1, 1), self.hidden_fc.bias)
         return torch.softmax(self.logits_fc(z), dim=1), torch.tanh(self.value_fc(z))
 

@@ -1108,7 +1108,7 @@ __global__ void k_stem_tables(int N, const float *w /*[16][N+1][3][3]*/, const f
 // loop over leaves -- the table rows a wave touches differ from lane to lane, which made the L1/L2 round trip of every
 // 64-byte row the kernel's critical path.  Larger tables (N > 40) stay in L2.
 template <typename row_t, bool T_LDS>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows, int nhwc) {
     extern __shared__ __attribute__((aligned(16))) float4 sT4[];
     const int lane = lane_id();
     if (T_LDS) {
@@ -1198,7 +1198,16 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                     for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[wx][o]);
                 }
             }
-            if (live) {
+            if (live && nhwc) {  // channels-last: a pixel's 16 channels are contiguous -> four 16-byte stores per lane
+                float4 *o4 = (float4 *)(ob + (size_t)pp * STEM_C);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = make_float4(best[4 * q], best[4 * q + 1], best[4 * q + 2], best[4 * q + 3]);
+                if (out_relu) {
+                    float4 *r4 = (float4 *)(out_relu + (size_t)b * STEM_C * P + (size_t)pp * STEM_C);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r4[q] = make_float4(fmaxf(best[4 * q], 0.f), fmaxf(best[4 * q + 1], 0.f), fmaxf(best[4 * q + 2], 0.f), fmaxf(best[4 * q + 3], 0.f));
+                }
+            } else if (live) {
 #pragma unroll
                 for (int o = 0; o < STEM_C; ++o) ob[(size_t)o * P + pp] = best[o];
                 if (out_relu) {
@@ -1605,6 +1614,31 @@ __global__ void k_nn_bias_pool(const float *x, const float *bias, float *out, fl
             int c = 2 * px + dx;
             if (c < 0 || c >= W) continue;
             m = fmaxf(m, xp[r * W + c] + b);
+        }
+    }
+    out[i] = m;
+    if (out_relu) out_relu[i] = m > 0.f ? m : 0.f;
+}
+// the same on channels-last data (x[b][r][c][ch]): one thread per output element, consecutive threads = consecutive channels
+__global__ void k_nn_bias_pool_nhwc(const float *x, const float *bias, float *out, float *out_relu, long long n_out, int C, int H, int W, int Hp, int Wp) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    int ch = (int)(i % C);
+    long long q = i / C;
+    int px = (int)(q % Wp), pr = (int)((q / Wp) % Hp);
+    long long b = q / ((long long)Wp * Hp);
+    const float *xb = x + b * (long long)H * W * C + ch;
+    const float bi = bias[ch];
+    float m = -INFINITY;
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+        int r = 2 * pr + dr;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            int c = 2 * px + dx;
+            if (c < 0 || c >= W) continue;
+            m = fmaxf(m, xb[((long long)r * W + c) * C] + bi);
         }
     }
     out[i] = m;
@@ -2032,7 +2066,7 @@ extern "C" int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const f
     return RP_OK;
 }
 
-extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, int64_t capacity_rows) {
+extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, int64_t capacity_rows, int32_t channels_last) {
     if (!ctx || !out_dev || capacity_rows < 0) return fail(ctx, RP_ERR_ARG, "rp_leaf_stem: bad argument");
     const DP &d = ctx->d;
     if (!d.stemT) return fail(ctx, RP_ERR_STATE, "rp_leaf_stem: call rp_stem_set_weights first");
@@ -2042,11 +2076,11 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     const bool t_lds = t_bytes <= 64 * 1024;
     const int grid = (int)std::min<long long>(grid_for(rows), t_lds ? 256 * 3 : 1 << 20);  // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32)
     if (ctx->row64) {
-        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
-        else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
+        else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
     } else {
-        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u32, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
-        else hipLaunchKernelGGL((k_leaf_stem<u32, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows);
+        if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u32, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
+        else hipLaunchKernelGGL((k_leaf_stem<u32, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
     }
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
@@ -2075,13 +2109,17 @@ extern "C" int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float 
 }
 
 extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bias_dev, float *out_dev, float *out_relu_dev, int64_t B, int32_t C, int32_t H,
-                               int32_t W) {
+                               int32_t W, int32_t channels_last) {
     if (!ctx || !x_dev || !bias_dev || !out_dev || B < 0 || C < 1 || H < 1 || W < 1) return fail(ctx, RP_ERR_ARG, "rp_nn_bias_pool: bad argument");
     int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
     long long n = (long long)B * C * Hp * Wp;
     if (n == 0) return RP_OK;
-    hipLaunchKernelGGL(k_nn_bias_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C, (int)H,
-                       (int)W, Hp, Wp);
+    if (channels_last)
+        hipLaunchKernelGGL(k_nn_bias_pool_nhwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C,
+                           (int)H, (int)W, Hp, Wp);
+    else
+        hipLaunchKernelGGL(k_nn_bias_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C, (int)H,
+                           (int)W, Hp, Wp);
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }

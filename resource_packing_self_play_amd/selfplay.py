@@ -36,7 +36,9 @@ class _Group:
         self.eng.set_step_cap(owner.step_cap)
         self.use_stem = owner.use_stem
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
-            self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device)
+            self.channels_last = owner.channels_last
+            fmt = torch.channels_last if self.channels_last else torch.contiguous_format
+            self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device).contiguous(memory_format=fmt)
             self.stem_relu = torch.zeros_like(self.stem) if owner.fuse_elementwise else None
             self.planes = None
         else:
@@ -58,7 +60,7 @@ class _Group:
     def wave_eager(self, nnet):
         self.eng.search_step(sync=False)
         if self.use_stem:
-            self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None)
+            self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None, self.channels_last)
         else:
             self.eng.leaf_planes(self.planes.data_ptr(), self.G)
         self.pi, self.v = self.forward(nnet)
@@ -67,7 +69,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, channels_last=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -83,6 +85,9 @@ class BatchedSelfPlay:
         self.use_stem = bool(use_stem)
         self.fuse_elementwise = bool(fuse_elementwise) and self.use_stem
         self.dense_small_convs = bool(dense_small_convs)
+        self.channels_last = bool(channels_last) and self.fuse_elementwise
+        if self.channels_last:  # convolution weights in NHWC too, so MIOpen never converts per call
+            nnet.nnet.to(memory_format=torch.channels_last)
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
         self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0

@@ -160,6 +160,7 @@ def test_engine_stem_matches_conv_and_pool(name):
     eng.stem_set_weights(w.data_ptr(), b.data_ptr())
     eng.begin_episodes(wh, np.full(games, W * H, np.int32))
     planes = torch.zeros((games, N + 1, H, W), device="cuda"); stem = torch.zeros((games, 16, (H + 1) // 2, (W + 1) // 2), device="cuda")
+    stem_cl = torch.zeros_like(stem).contiguous(memory_format=torch.channels_last); stem_cl_relu = torch.zeros_like(stem_cl)
     conv = net.nnet.conv_seqs[0].conv
     worst_stem = worst_pi = 0.0
     checked = 0
@@ -169,9 +170,11 @@ def test_engine_stem_matches_conv_and_pool(name):
             continue  # every slot is between two moves (played at the start of the next step)
         checked += 1
         eng.leaf_planes(planes.data_ptr(), games); eng.leaf_stem(stem.data_ptr(), games)
+        eng.leaf_stem(stem_cl.data_ptr(), games, stem_cl_relu.data_ptr(), channels_last=True)
         with torch.no_grad():
             want = F.max_pool2d(conv(planes[:n]), kernel_size=3, stride=2, padding=1)
         worst_stem = max(worst_stem, float((stem[:n] - want).abs().max()))
+        assert torch.equal(stem_cl[:n], stem[:n]) and torch.equal(stem_cl_relu[:n], torch.relu(stem[:n]))  # same numbers, NHWC order
         pi_a, v_a = net.predict_batch(planes[:n]); pi_b, v_b = net.predict_from_stem(stem[:n])
         worst_pi = max(worst_pi, float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max()))
         eng.commit_eval(pi_a.data_ptr(), v_a.data_ptr()) if n == games else eng.commit_eval_host(pi_a.cpu().numpy(), v_a.cpu().numpy())
@@ -209,6 +212,13 @@ def test_fused_elementwise_forward_matches_plain_forward(name):
     dpi, dv = float((pi_a - pi_c).abs().max()), float((v_a - v_c).abs().max())
     print("fused+dense vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
     assert dpi <= 1e-6 and dv <= 1e-6
+    # channels-last activations through the same kernels
+    ycl = y.contiguous(memory_format=torch.channels_last)
+    pi_d, v_d = net.predict_from_stem(ycl, torch.relu(ycl), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_d).abs().max()), float((v_a - v_d).abs().max())
+    print("fused+dense channels-last vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-6
     net.nnet._dense.clear()
     # the three kernels on their own
     x = torch.randn(33, 32, 5, 5, device="cuda"); b = torch.randn(32, device="cuda"); r = torch.randn_like(x)
@@ -223,4 +233,10 @@ def test_fused_elementwise_forward_matches_plain_forward(name):
     wantp = torch.nn.functional.max_pool2d(x + b.view(1, -1, 1, 1), 3, 2, 1)
     torch.cuda.synchronize()
     assert torch.equal(po, wantp) and torch.equal(po_r, torch.relu(wantp))
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    pc = torch.empty(33, 32, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last); pc_r = torch.empty_like(pc)
+    eng.nn_bias_pool(xcl, b, pc, pc_r)
+    got_cl = eng.nn_bias_relu(xcl[:32].clone(memory_format=torch.channels_last), b)
+    torch.cuda.synchronize()
+    assert torch.equal(pc, wantp) and torch.equal(pc_r, torch.relu(wantp)) and torch.equal(got_cl, want[:32])
     eng.close()
