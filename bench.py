@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-fuse", action="store_true", help="leave bias / ReLU / skip / pool to PyTorch's own element-wise kernels")
     ap.add_argument("--no-dense", action="store_true", help="keep <= 3x3-image convolutions on MIOpen instead of one GEMM each")
+    ap.add_argument("--no-resblock", action="store_true", help="16-channel residual blocks through MIOpen + fused element-wise kernels instead of rp_nn_resblock16")
     ap.add_argument("--nchw", action="store_true", help="keep the evaluator's activations NCHW instead of channels-last")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,7 +194,7 @@ def main():
     node_cap = sims * (N + 1) + 2
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
-                         reclaim=not a.no_reclaim, vis_cap=int(node_cap * a.vis_factor), channels_last=not a.nchw)
+                         reclaim=not a.no_reclaim, vis_cap=int(node_cap * a.vis_factor), channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)

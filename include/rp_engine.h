@@ -179,6 +179,12 @@ int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), 
  *   rp_nn_bias_residual  out = (x + bias[c]) + res ; out_relu = relu(out)            (out_relu may be NULL)
  *   rp_nn_bias_pool      out = max_pool2d(x + bias[c], 3, stride 2, pad 1) ; out_relu = relu(out)
  * Channels-last tensors: call the first two with (B*H*W, C, 1), the pool with channels_last = 1. */
+/* Fused residual block of the 16-channel stage on the FP32 matrix cores, channels-last [B][H][W][16]:
+ *   out = x + conv1(relu(conv0(relu(x)) + b0)) + b1 ; out_relu = relu(out)   (BinpackingNNet.py:21-27)
+ * rp_nn_pack_conv16 reorders a contiguous [16][16][3][3] weight into MFMA B-fragment order ([36][64] floats). */
+int rp_nn_pack_conv16(rp_ctx *ctx, const float *w_dev, float *frag_dev);
+int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, const float *bias0_dev, const float *frag1_dev, const float *bias1_dev,
+                     float *out_dev, float *out_relu_dev /* may be NULL */, int64_t B, int32_t H, int32_t W);
 int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
                         int64_t B, int32_t C, int32_t HW);

@@ -63,6 +63,8 @@ _SIGS = {
     "rp_leaf_planes": (C.c_int, [_vp, _vp, _i64]),
     "rp_stem_set_weights": (C.c_int, [_vp, _vp, _vp]),
     "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64, _i32]),
+    "rp_nn_pack_conv16": (C.c_int, [_vp, _vp, _vp]),
+    "rp_nn_resblock16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32]),
@@ -276,6 +278,19 @@ class Engine:
         if not x.is_contiguous():
             raise ValueError("tensor must be contiguous")
         return x.shape[0], x.shape[1], x[0, 0].numel()
+
+    def nn_pack_conv16(self, weight, frag):
+        """weight: contiguous float32 [16, 16, 3, 3]; frag: float32 [36 * 64] buffer to fill (MFMA B-fragment order)."""
+        self._ck(self.L.rp_nn_pack_conv16(self.h, C.c_void_p(weight.data_ptr()), C.c_void_p(frag.data_ptr())))
+
+    def nn_resblock16(self, x, frag0, bias0, frag1, bias1, out, out_relu=None):
+        """Fused 16-channel residual block on channels-last x [B, 16, H, W]."""
+        B, Cc, H, W = x.shape
+        if Cc != 16 or self._bchw(x)[2] != 1:
+            raise ValueError("nn_resblock16 needs a channels-last [B, 16, H, W] tensor")
+        self._ck(self.L.rp_nn_resblock16(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag0.data_ptr()), C.c_void_p(bias0.data_ptr()),
+                                         C.c_void_p(frag1.data_ptr()), C.c_void_p(bias1.data_ptr()), C.c_void_p(out.data_ptr()),
+                                         C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
 
     def nn_bias_relu(self, x, bias):
         B, Cc, inner = self._bchw(x)

@@ -89,6 +89,7 @@ class BinPackingNNet(nn.Module):
     # entry is exactly one weight) and refreshed in place after weight updates, which keeps captured HIP graphs valid.
     # Both memory orders are kept: NCHW-flattened (c, h, w) and channels-last-flattened (h, w, c).
     DENSE_MAX_PIXELS = 9
+    use_resblock_kernel = True
 
     def _set_cached(self, key, value):
         if not hasattr(self, "_dense"):
@@ -116,6 +117,26 @@ class BinPackingNNet(nn.Module):
             ch, h, w = shapes[-1]  # hidden_fc on channels-last features: columns reordered from (c, h, w) to (h, w, c)
             self._set_cached("hidden:cl", self.hidden_fc.weight.view(-1, ch, h, w).permute(0, 2, 3, 1).reshape(self.hidden_fc.out_features, -1))
         return self._dense
+
+    def refresh_frags(self, ops):
+        """MFMA B-fragment copies of the 16-channel stage's residual convolutions for the engine's fused block kernel
+        (rp_nn_resblock16); refreshed in place after weight updates."""
+        if not hasattr(self, "_dense"):
+            self._dense = {}
+        keep = []
+        with torch.no_grad():
+            for si, stage in enumerate(self.conv_seqs):
+                if stage.conv.out_channels != 16:
+                    continue
+                for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
+                    for ci, conv in enumerate((blk.conv0, blk.conv1)):
+                        key = "frag:%d:b%dc%d" % (si, bi, ci)
+                        if key not in self._dense:
+                            self._dense[key] = torch.empty(36 * 64, device=conv.weight.device, dtype=torch.float32)
+                        w = conv.weight.detach().contiguous()  # plain [16][16][3][3] order whatever the parameter's format
+                        keep.append(w)
+                        ops.nn_pack_conv16(w, self._dense[key])
+        return keep
 
     @staticmethod
     def _is_cl(x):
@@ -149,6 +170,12 @@ class BinPackingNNet(nn.Module):
                 xr = torch.empty_like(x)
                 ops.nn_bias_pool(c, stage.conv.bias, x, xr)
             for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
+                f0 = getattr(self, "_dense", {}).get("frag:%d:b%dc0" % (si, bi)) if cl and self.use_resblock_kernel else None
+                if f0 is not None:  # whole block in one kernel on the FP32 matrix cores
+                    out, out_r = torch.empty_like(x), torch.empty_like(x)
+                    ops.nn_resblock16(x, f0, blk.conv0.bias, self._dense["frag:%d:b%dc1" % (si, bi)], blk.conv1.bias, out, out_r)
+                    x, xr = out, out_r
+                    continue
                 c0 = self._conv_nobias(xr, blk.conv0, si, "b%dc0" % bi)
                 ops.nn_bias_relu(c0, blk.conv0.bias)
                 c1 = self._conv_nobias(c0, blk.conv1, si, "b%dc1" % bi)

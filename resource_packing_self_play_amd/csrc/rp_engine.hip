@@ -1646,6 +1646,107 @@ __global__ void k_nn_bias_pool_nhwc(const float *x, const float *bias, float *ou
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused residual block for the 16-channel stage (BinpackingNNet.py:15-27):
+//     y = x + conv1(relu(conv0(relu(x)) + b0)) + b1 ,   3x3 convolutions, pad 1, 16 -> 16 channels, channels-last FP32
+// as two implicit GEMMs on the FP32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32 fma chains).  One wave per leaf:
+// M = pixels (tiles of 16), N = 16 output channels, K = 9 taps x 16 input channels = 36 k-steps of 4.  The B fragments of
+// both convolutions (72 VGPRs) are loaded once per wave and reused for every leaf it processes; relu(x) and the
+// intermediate live in zero-bordered LDS images with a 17-float pixel stride (bank-conflict-free A-fragment reads with
+// constant offsets per k-step).  Replaces 2 MIOpen convolutions + 2 element-wise kernels and their HBM round trips.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define RB_STRIDE 17
+#define RB_TILES 8
+// fragment order of a [16][16][3][3] weight: frag[s][lane] = W[co = lane & 15][ci = 4 * (s & 3) + (lane >> 4)][tap = s >> 2]
+__global__ void k_pack_conv16(const float *w, float *frag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 36 * 64) return;
+    int s = i >> 6, l = i & 63;
+    int co = l & 15, ci = 4 * (s & 3) + (l >> 4), tap = s >> 2;
+    frag[i] = w[(co * 16 + ci) * 9 + tap];
+}
+__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, int PIX, int S_w, int tile0, int ntiles, f32x4 (&acc)[RB_TILES]) {
+    const int lane = lane_id();
+    int base[RB_TILES];
+#pragma unroll
+    for (int t = 0; t < RB_TILES; ++t) {
+        int m = (tile0 + t) * 16 + (lane & 15);
+        if (m >= PIX) m = 0;
+        int r = m / S_w, c = m - r * S_w;
+        base[t] = (r * PW + c) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window in padded coordinates
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+        const int tap = s >> 2, dr = tap / 3, dx = tap - 3 * dr;
+        const int off = (dr * PW + dx) * RB_STRIDE + 4 * (s & 3);
+#pragma unroll
+        for (int t = 0; t < RB_TILES; ++t)
+            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(img[base[t] + off], bf[s], acc[t], 0, 0, 0);
+    }
+}
+__global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
+                                                    float *out_relu, long long B, int S_h, int S_w) {
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE;
+    float *img0 = rb_lds + (size_t)wv * 2 * IMG, *img1 = img0 + IMG;
+    for (int i = lane; i < 2 * IMG; i += 64) img0[i] = 0.f;  // borders stay zero for the whole launch
+    float bf0[36], bf1[36];
+#pragma unroll
+    for (int s = 0; s < 36; ++s) { bf0[s] = frag0[s * 64 + lane]; bf1[s] = frag1[s * 64 + lane]; }
+    const float bias0v = bias0[lane & 15], bias1v = bias1[lane & 15];
+    const int ntiles_all = (PIX + 15) >> 4;
+    wave_sync();
+    for (long long leaf = (long long)blockIdx.x * 4 + wv; leaf < B; leaf += (long long)gridDim.x * 4) {
+        const float *xl = x + (size_t)leaf * PIX * 16;
+        for (int e = lane; e < PIX * 16; e += 64) {  // relu(x) into the padded image
+            int pix = e >> 4, c = e & 15, r = pix / S_w, cc = pix - r * S_w;
+            img0[((r + 1) * PW + cc + 1) * RB_STRIDE + c] = fmaxf(xl[e], 0.f);
+        }
+        wave_sync();
+        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {  // conv0 -> relu(. + b0) -> img1
+            const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
+            f32x4 acc[RB_TILES];
+            rb_conv(img0, bf0, PW, PIX, S_w, tile0, nt, acc);
+#pragma unroll
+            for (int t = 0; t < RB_TILES; ++t) {
+                if (t >= nt) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
+                    if (m < PIX) {
+                        int r = m / S_w, cc = m - r * S_w;
+                        img1[((r + 1) * PW + cc + 1) * RB_STRIDE + (lane & 15)] = fmaxf(acc[t][q] + bias0v, 0.f);
+                    }
+                }
+            }
+        }
+        wave_sync();
+        float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
+        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {  // conv1 -> (. + b1) + x
+            const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
+            f32x4 acc[RB_TILES];
+            rb_conv(img1, bf1, PW, PIX, S_w, tile0, nt, acc);
+#pragma unroll
+            for (int t = 0; t < RB_TILES; ++t) {
+                if (t >= nt) break;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
+                    if (m < PIX) {
+                        float y = (acc[t][q] + bias1v) + xl[m * 16 + (lane & 15)];
+                        ol[m * 16 + (lane & 15)] = y;
+                        if (orl) orl[m * 16 + (lane & 15)] = fmaxf(y, 0.f);
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct rp_ctx {
@@ -2120,6 +2221,29 @@ extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bia
     else
         hipLaunchKernelGGL(k_nn_bias_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C, (int)H,
                            (int)W, Hp, Wp);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_pack_conv16(rp_ctx *ctx, const float *w_dev, float *frag_dev) {
+    if (!ctx || !w_dev || !frag_dev) return fail(ctx, RP_ERR_ARG, "rp_nn_pack_conv16: bad argument");
+    hipLaunchKernelGGL(k_pack_conv16, dim3(9), dim3(256), 0, ctx->stream, w_dev, frag_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, const float *bias0_dev, const float *frag1_dev, const float *bias1_dev,
+                                float *out_dev, float *out_relu_dev, int64_t B, int32_t H, int32_t W) {
+    if (!ctx || !x_dev || !frag0_dev || !bias0_dev || !frag1_dev || !bias1_dev || !out_dev || B < 0 || H < 1 || W < 1 || H > 62 || W > 62)
+        return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: bad argument");
+    if (B == 0) return RP_OK;
+    const size_t lds = (size_t)4 * 2 * (H + 2) * (W + 2) * RB_STRIDE * sizeof(float);
+    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: %dx%d image does not fit LDS", H, W);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
+    const int grid = (int)std::min<long long>((B + 3) / 4, 256LL * per_cu);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resblock16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_resblock16, dim3(grid), dim3(256), lds, ctx->stream, x_dev, frag0_dev, bias0_dev, frag1_dev, bias1_dev, out_dev, out_relu_dev, (long long)B,
+                       (int)H, (int)W);
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }

@@ -37,6 +37,7 @@ class _Group:
         self.use_stem = owner.use_stem
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
             self.channels_last = owner.channels_last
+            self.resblock_kernel = owner.resblock_kernel
             fmt = torch.channels_last if self.channels_last else torch.contiguous_format
             self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device).contiguous(memory_format=fmt)
             self.stem_relu = torch.zeros_like(self.stem) if owner.fuse_elementwise else None
@@ -51,6 +52,8 @@ class _Group:
             w, b = nnet.stem_params()
             self._stem_w, self._stem_b = w, b  # keep alive until the table kernel ran
             self.eng.stem_set_weights(w.data_ptr(), b.data_ptr())
+            if self.stem_relu is not None and self.channels_last and self.resblock_kernel:
+                self._frag_src = nnet.nnet.refresh_frags(self.eng)
 
     def forward(self, nnet):
         if self.use_stem:
@@ -69,7 +72,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, channels_last=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, channels_last=True, resblock_kernel=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -86,6 +89,8 @@ class BatchedSelfPlay:
         self.fuse_elementwise = bool(fuse_elementwise) and self.use_stem
         self.dense_small_convs = bool(dense_small_convs)
         self.channels_last = bool(channels_last) and self.fuse_elementwise
+        self.resblock_kernel = bool(resblock_kernel) and self.channels_last
+        nnet.nnet.use_resblock_kernel = self.resblock_kernel
         if self.channels_last:  # convolution weights in NHWC too, so MIOpen never converts per call
             nnet.nnet.to(memory_format=torch.channels_last)
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]

@@ -240,3 +240,38 @@ def test_fused_elementwise_forward_matches_plain_forward(name):
     torch.cuda.synchronize()
     assert torch.equal(pc, wantp) and torch.equal(pc_r, torch.relu(wantp)) and torch.equal(got_cl, want[:32])
     eng.close()
+
+
+def test_fused_resblock16_kernel_matches_pytorch_block():
+    """rp_nn_resblock16 (two 3x3 convolutions on the FP32 matrix cores + ReLUs + skip, channels-last) against the module's
+    residual block through PyTorch."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    d = np.load(os.path.join(GOLDEN, "nnet_c3_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    eng = _lib.Engine(20, 20, 32, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(3)
+    for (B, H, W) in [(5, 10, 10), (1030, 10, 10), (64, 7, 9), (33, 3, 3), (17, 13, 12)]:
+        blk = net.nnet.conv_seqs[0].res_block1
+        x = torch.randn(B, 16, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            want = blk(x)
+        f0 = torch.empty(36 * 64, device="cuda"); f1 = torch.empty(36 * 64, device="cuda")
+        eng.nn_pack_conv16(blk.conv0.weight.detach().contiguous(), f0); eng.nn_pack_conv16(blk.conv1.weight.detach().contiguous(), f1)
+        out, out_r = torch.empty_like(x), torch.empty_like(x)
+        eng.nn_resblock16(x, f0, blk.conv0.bias.detach(), f1, blk.conv1.bias.detach(), out, out_r)
+        torch.cuda.synchronize()
+        err = float((out - want).abs().max())
+        print("resblock16 B=%d %dx%d: max |delta| %.3e" % (B, H, W, err))
+        assert err <= 2e-5 and torch.equal(out_r, torch.relu(out))
+    # and the whole evaluator through it
+    y = torch.randn(300, 16, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
+    pi_a, v_a = net.predict_from_stem(y)
+    net.refresh_fused(); keep = net.nnet.refresh_frags(eng)
+    pi_b, v_b = net.predict_from_stem(y, torch.relu(y), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max())
+    print("evaluator with the block kernel vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-5
+    net.nnet._dense.clear()
+    eng.close()
