@@ -1665,69 +1665,74 @@ __global__ void k_pack_conv16(const float *w, float *frag) {
     int co = l & 15, ci = 4 * (s & 3) + (l >> 4), tap = s >> 2;
     frag[i] = w[(co * 16 + ci) * 9 + tap];
 }
-__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, int PIX, int S_w, int tile0, int ntiles, f32x4 (&acc)[RB_TILES]) {
-    const int lane = lane_id();
-    int base[RB_TILES];
+// accumulate one convolution for up to RB_TILES pixel tiles; abase[t] = LDS offset of lane's pixel (top-left tap) + its k sub-index
+__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, const int (&abase)[RB_TILES], int ntiles, f32x4 (&acc)[RB_TILES]) {
 #pragma unroll
-    for (int t = 0; t < RB_TILES; ++t) {
-        int m = (tile0 + t) * 16 + (lane & 15);
-        if (m >= PIX) m = 0;
-        int r = m / S_w, c = m - r * S_w;
-        base[t] = (r * PW + c) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window in padded coordinates
-        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int t = 0; t < RB_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
         const int tap = s >> 2, dr = tap / 3, dx = tap - 3 * dr;
         const int off = (dr * PW + dx) * RB_STRIDE + 4 * (s & 3);
 #pragma unroll
         for (int t = 0; t < RB_TILES; ++t)
-            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(img[base[t] + off], bf[s], acc[t], 0, 0, 0);
+            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(img[abase[t] + off], bf[s], acc[t], 0, 0, 0);
     }
 }
-__global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
+__global__ void __launch_bounds__(256, 2) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
                                                     float *out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE;
-    float *img0 = rb_lds + (size_t)wv * 2 * IMG, *img1 = img0 + IMG;
+    int *ptab = (int *)rb_lds;                       // [PIX] padded LDS offset of every pixel's channel 0 (shared by the block)
+    float *img0 = rb_lds + ((PIX + 3) & ~3) + (size_t)wv * 2 * IMG, *img1 = img0 + IMG;
+    for (int i = threadIdx.x; i < PIX; i += blockDim.x) { int r = i / S_w, c = i - r * S_w; ptab[i] = ((r + 1) * PW + c + 1) * RB_STRIDE; }
     for (int i = lane; i < 2 * IMG; i += 64) img0[i] = 0.f;  // borders stay zero for the whole launch
     float bf0[36], bf1[36];
 #pragma unroll
     for (int s = 0; s < 36; ++s) { bf0[s] = frag0[s * 64 + lane]; bf1[s] = frag1[s * 64 + lane]; }
     const float bias0v = bias0[lane & 15], bias1v = bias1[lane & 15];
     const int ntiles_all = (PIX + 15) >> 4;
-    wave_sync();
+    __syncthreads();
     for (long long leaf = (long long)blockIdx.x * 4 + wv; leaf < B; leaf += (long long)gridDim.x * 4) {
         const float *xl = x + (size_t)leaf * PIX * 16;
-        for (int e = lane; e < PIX * 16; e += 64) {  // relu(x) into the padded image
-            int pix = e >> 4, c = e & 15, r = pix / S_w, cc = pix - r * S_w;
-            img0[((r + 1) * PW + cc + 1) * RB_STRIDE + c] = fmaxf(xl[e], 0.f);
+        for (int e4 = lane; e4 < PIX * 4; e4 += 64) {  // relu(x) into the padded image, 16 bytes per lane
+            float4 v = ((const float4 *)xl)[e4];
+            float *d = img0 + ptab[e4 >> 2] + 4 * (e4 & 3);
+            d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
         }
         wave_sync();
-        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {  // conv0 -> relu(. + b0) -> img1
+        float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
+        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
             const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
+            int abase[RB_TILES];
+#pragma unroll
+            for (int t = 0; t < RB_TILES; ++t) {
+                int m = (tile0 + t) * 16 + (lane & 15);
+                abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+            }
             f32x4 acc[RB_TILES];
-            rb_conv(img0, bf0, PW, PIX, S_w, tile0, nt, acc);
+            rb_conv(img0, bf0, PW, abase, nt, acc);  // conv0 -> relu(. + b0) -> img1
 #pragma unroll
             for (int t = 0; t < RB_TILES; ++t) {
                 if (t >= nt) break;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
-                    if (m < PIX) {
-                        int r = m / S_w, cc = m - r * S_w;
-                        img1[((r + 1) * PW + cc + 1) * RB_STRIDE + (lane & 15)] = fmaxf(acc[t][q] + bias0v, 0.f);
-                    }
+                    if (m < PIX) img1[ptab[m] + (lane & 15)] = fmaxf(acc[t][q] + bias0v, 0.f);
                 }
             }
         }
         wave_sync();
-        float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
-        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {  // conv1 -> (. + b1) + x
+        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
             const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
+            int abase[RB_TILES];
+#pragma unroll
+            for (int t = 0; t < RB_TILES; ++t) {
+                int m = (tile0 + t) * 16 + (lane & 15);
+                abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);
+            }
             f32x4 acc[RB_TILES];
-            rb_conv(img1, bf1, PW, PIX, S_w, tile0, nt, acc);
+            rb_conv(img1, bf1, PW, abase, nt, acc);  // conv1 -> (. + b1) + x
 #pragma unroll
             for (int t = 0; t < RB_TILES; ++t) {
                 if (t >= nt) break;
@@ -2237,7 +2242,7 @@ extern "C" int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *fr
     if (!ctx || !x_dev || !frag0_dev || !bias0_dev || !frag1_dev || !bias1_dev || !out_dev || B < 0 || H < 1 || W < 1 || H > 62 || W > 62)
         return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: bad argument");
     if (B == 0) return RP_OK;
-    const size_t lds = (size_t)4 * 2 * (H + 2) * (W + 2) * RB_STRIDE * sizeof(float);
+    const size_t lds = ((size_t)4 * 2 * (H + 2) * (W + 2) * RB_STRIDE + (((size_t)H * W + 3) & ~(size_t)3)) * sizeof(float);
     if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: %dx%d image does not fit LDS", H, W);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
     const int grid = (int)std::min<long long>((B + 3) / 4, 256LL * per_cu);
