@@ -1656,7 +1656,7 @@ __global__ void k_nn_bias_pool_nhwc(const float *x, const float *bias, float *ou
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_STRIDE 17
-#define RB_TILES 8
+#define RB_TILES 7
 // fragment order of a [16][16][3][3] weight: frag[s][lane] = W[co = lane & 15][ci = 4 * (s & 3) + (lane >> 4)][tap = s >> 2]
 __global__ void k_pack_conv16(const float *w, float *frag) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1666,9 +1666,14 @@ __global__ void k_pack_conv16(const float *w, float *frag) {
     frag[i] = w[(co * 16 + ci) * 9 + tap];
 }
 // accumulate one convolution for up to RB_TILES pixel tiles; abase[t] = LDS offset of lane's pixel (top-left tap) + its k sub-index
-__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, const int (&abase)[RB_TILES], int ntiles, f32x4 (&acc)[RB_TILES]) {
+__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, int PIX, const int *ptab, int tile0, int ntiles, f32x4 (&acc)[RB_TILES]) {
+    int abase[RB_TILES];
 #pragma unroll
-    for (int t = 0; t < RB_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RB_TILES; ++t) {
+        int m = (tile0 + t) * 16 + (lane_id() & 15);
+        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane_id() >> 4);  // top-left tap of the 3x3 window
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
         const int tap = s >> 2, dr = tap / 3, dx = tap - 3 * dr;
@@ -1678,7 +1683,7 @@ __device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36],
             if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(img[abase[t] + off], bf[s], acc[t], 0, 0, 0);
     }
 }
-__global__ void __launch_bounds__(256, 2) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
+__global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
                                                     float *out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -1704,14 +1709,8 @@ __global__ void __launch_bounds__(256, 2) k_resblock16(const float *x, const flo
         float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
         for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
             const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
-            int abase[RB_TILES];
-#pragma unroll
-            for (int t = 0; t < RB_TILES; ++t) {
-                int m = (tile0 + t) * 16 + (lane & 15);
-                abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
-            }
             f32x4 acc[RB_TILES];
-            rb_conv(img0, bf0, PW, abase, nt, acc);  // conv0 -> relu(. + b0) -> img1
+            rb_conv(img0, bf0, PW, PIX, ptab, tile0, nt, acc);  // conv0 -> relu(. + b0) -> img1
 #pragma unroll
             for (int t = 0; t < RB_TILES; ++t) {
                 if (t >= nt) break;
@@ -1725,14 +1724,8 @@ __global__ void __launch_bounds__(256, 2) k_resblock16(const float *x, const flo
         wave_sync();
         for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
             const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
-            int abase[RB_TILES];
-#pragma unroll
-            for (int t = 0; t < RB_TILES; ++t) {
-                int m = (tile0 + t) * 16 + (lane & 15);
-                abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);
-            }
             f32x4 acc[RB_TILES];
-            rb_conv(img1, bf1, PW, abase, nt, acc);  // conv1 -> (. + b1) + x
+            rb_conv(img1, bf1, PW, PIX, ptab, tile0, nt, acc);  // conv1 -> (. + b1) + x
 #pragma unroll
             for (int t = 0; t < RB_TILES; ++t) {
                 if (t >= nt) break;
