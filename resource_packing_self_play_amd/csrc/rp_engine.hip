@@ -1674,15 +1674,26 @@ __device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36],
         abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane_id() >> 4);  // top-left tap of the 3x3 window
         acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // software pipeline: the A fragments of k-step s+1 are read from LDS while the matrix cores work on step s
+    float a_cur[RB_TILES], a_nxt[RB_TILES];
+#pragma unroll
+    for (int t = 0; t < RB_TILES; ++t) a_cur[t] = img[abase[t]];
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
-        const int tap = s >> 2, dr = tap / 3, dx = tap - 3 * dr;
-        const int off = (dr * PW + dx) * RB_STRIDE + 4 * (s & 3);
+        if (s + 1 < 36) {
+            const int tap = (s + 1) >> 2, dr = tap / 3, dx = tap - 3 * dr;
+            const int off = (dr * PW + dx) * RB_STRIDE + 4 * ((s + 1) & 3);
+#pragma unroll
+            for (int t = 0; t < RB_TILES; ++t) a_nxt[t] = img[abase[t] + off];
+        }
 #pragma unroll
         for (int t = 0; t < RB_TILES; ++t)
-            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(img[abase[t] + off], bf[s], acc[t], 0, 0, 0);
+            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], bf[s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RB_TILES; ++t) a_cur[t] = a_nxt[t];
     }
 }
+
 __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
                                                     float *out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
