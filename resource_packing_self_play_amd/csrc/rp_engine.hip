@@ -1665,35 +1665,70 @@ __global__ void k_pack_conv16(const float *w, float *frag) {
     int co = l & 15, ci = 4 * (s & 3) + (l >> 4), tap = s >> 2;
     frag[i] = w[(co * 16 + ci) * 9 + tap];
 }
-// accumulate one convolution for up to RB_TILES pixel tiles; abase[t] = LDS offset of lane's pixel (top-left tap) + its k sub-index
-__device__ __forceinline__ void rb_conv(const float *img, const float (&bf)[36], int PW, int PIX, const int *ptab, int tile0, int ntiles, f32x4 (&acc)[RB_TILES]) {
-    int abase[RB_TILES];
+// One convolution over NT pixel tiles starting at tile0 (NT is a compile-time count: no predicates inside the MFMA stream).
+// EPI 0: relu(acc + bias) -> padded LDS image (input of the second convolution)
+// EPI 1: (acc + bias) + x -> out (and relu -> out_relu)
+template <int NT, int EPI>
+__device__ __forceinline__ void rb_conv_tiles(const float *img, const float (&bf)[36], float biasv, int PW, int PIX, const int *ptab, int tile0, float *img_out,
+                                              const float *xl, float *ol, float *orl) {
+    const int lane = lane_id();
+    int abase[NT];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < RB_TILES; ++t) {
-        int m = (tile0 + t) * 16 + (lane_id() & 15);
-        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane_id() >> 4);  // top-left tap of the 3x3 window
+    for (int t = 0; t < NT; ++t) {
+        int m = (tile0 + t) * 16 + (lane & 15);
+        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
         acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // software pipeline: the A fragments of k-step s+1 are read from LDS while the matrix cores work on step s
-    float a_cur[RB_TILES], a_nxt[RB_TILES];
+    float a_cur[NT], a_nxt[NT];
 #pragma unroll
-    for (int t = 0; t < RB_TILES; ++t) a_cur[t] = img[abase[t]];
+    for (int t = 0; t < NT; ++t) a_cur[t] = img[abase[t]];
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
         if (s + 1 < 36) {
             const int tap = (s + 1) >> 2, dr = tap / 3, dx = tap - 3 * dr;
             const int off = (dr * PW + dx) * RB_STRIDE + 4 * ((s + 1) & 3);
 #pragma unroll
-            for (int t = 0; t < RB_TILES; ++t) a_nxt[t] = img[abase[t] + off];
+            for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
         }
 #pragma unroll
-        for (int t = 0; t < RB_TILES; ++t)
-            if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], bf[s], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], bf[s], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < RB_TILES; ++t) a_cur[t] = a_nxt[t];
+        for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
+            if (m < PIX) {
+                if (EPI == 0) {
+                    img_out[ptab[m] + (lane & 15)] = fmaxf(acc[t][q] + biasv, 0.f);
+                } else {
+                    float y = (acc[t][q] + biasv) + xl[m * 16 + (lane & 15)];
+                    ol[m * 16 + (lane & 15)] = y;
+                    if (orl) orl[m * 16 + (lane & 15)] = fmaxf(y, 0.f);
+                }
+            }
+        }
     }
 }
-
+template <int EPI>
+__device__ __forceinline__ void rb_conv_all(const float *img, const float (&bf)[36], float biasv, int PW, int PIX, const int *ptab, int ntiles_all, float *img_out,
+                                            const float *xl, float *ol, float *orl) {
+    int tile0 = 0;
+    for (; tile0 + RB_TILES <= ntiles_all; tile0 += RB_TILES) rb_conv_tiles<RB_TILES, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl);
+    switch (ntiles_all - tile0) {  // uniform: the remainder group
+        case 1: rb_conv_tiles<1, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        case 2: rb_conv_tiles<2, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        case 3: rb_conv_tiles<3, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        case 4: rb_conv_tiles<4, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        case 5: rb_conv_tiles<5, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        case 6: rb_conv_tiles<6, EPI>(img, bf, biasv, PW, PIX, ptab, tile0, img_out, xl, ol, orl); break;
+        default: break;
+    }
+}
 __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
                                                     float *out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
@@ -1717,40 +1752,10 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
             d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
         }
         wave_sync();
-        float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
-        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
-            const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
-            f32x4 acc[RB_TILES];
-            rb_conv(img0, bf0, PW, PIX, ptab, tile0, nt, acc);  // conv0 -> relu(. + b0) -> img1
-#pragma unroll
-            for (int t = 0; t < RB_TILES; ++t) {
-                if (t >= nt) break;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
-                    if (m < PIX) img1[ptab[m] + (lane & 15)] = fmaxf(acc[t][q] + bias0v, 0.f);
-                }
-            }
-        }
+        rb_conv_all<0>(img0, bf0, bias0v, PW, PIX, ptab, ntiles_all, img1, nullptr, nullptr, nullptr);
         wave_sync();
-        for (int tile0 = 0; tile0 < ntiles_all; tile0 += RB_TILES) {
-            const int nt = ntiles_all - tile0 < RB_TILES ? ntiles_all - tile0 : RB_TILES;
-            f32x4 acc[RB_TILES];
-            rb_conv(img1, bf1, PW, PIX, ptab, tile0, nt, acc);  // conv1 -> (. + b1) + x
-#pragma unroll
-            for (int t = 0; t < RB_TILES; ++t) {
-                if (t >= nt) break;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int m = (tile0 + t) * 16 + (lane >> 4) * 4 + q;
-                    if (m < PIX) {
-                        float y = (acc[t][q] + bias1v) + xl[m * 16 + (lane & 15)];
-                        ol[m * 16 + (lane & 15)] = y;
-                        if (orl) orl[m * 16 + (lane & 15)] = fmaxf(y, 0.f);
-                    }
-                }
-            }
-        }
+        rb_conv_all<1>(img1, bf1, bias1v, PW, PIX, ptab, ntiles_all, nullptr, xl, out + (size_t)leaf * PIX * 16,
+                       out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr);
         wave_sync();
     }
 }
