@@ -192,9 +192,12 @@ def main():
     nnet = NNetWrapper(game, args)
     pool = a.pool or a.games
     node_cap = sims * (N + 1) + 2
+    edge_cap, vis_cap = node_cap * a.edge_factor, int(node_cap * a.vis_factor)
+    if sims < 100:  # short profiling budgets: one open chunk per reachable level dominates the arena, not the entry count
+        edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * 4096), max(vis_cap, (min(sims, N) + 3) * 1024)
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
-                         edge_cap=node_cap * a.edge_factor, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
-                         reclaim=not a.no_reclaim, vis_cap=int(node_cap * a.vis_factor), channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
+                         edge_cap=edge_cap, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
+                         reclaim=not a.no_reclaim, vis_cap=vis_cap, channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)

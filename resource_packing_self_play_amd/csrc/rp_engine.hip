@@ -1134,71 +1134,81 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
         if (lane < p.N) wh_lo = t.wh[2 * lane] | (t.wh[2 * lane + 1] << 8);
         if (lane + 64 < p.N) wh_hi = t.wh[2 * (lane + 64)] | (t.wh[2 * (lane + 64) + 1] << 8);
         float *ob = out + (size_t)b * STEM_C * P;
-        for (int base = 0; base < P; base += 64) {
-            const int pp = base + lane;
-            const bool live = pp < P;
-            const int pr = live ? pp / p.Wp : 0, px = live ? pp - (pp / p.Wp) * p.Wp : 0;
-            row_t rw[5];  // grid rows 2pr-2 .. 2pr+2 (zero outside the grid); shuffles need every lane
+        // A lane owns the 2x2 block of convolution outputs (2pr + {0,1}, 2px + {0,1}) of pooled pixel (pr, px): every output is
+        // computed exactly once; the 3x3/2 window's other five outputs come from the left / upper / upper-left lanes by
+        // shuffle.  A pass covers rpp pooled rows; passes after the first start one row early (halo row: computed, not stored).
+        const int rpp = 64 / p.Wp;
+        const int lr = lane / p.Wp, px = lane - lr * p.Wp;
+        for (int base = 0, pass = 0; base + (pass ? 1 : 0) < p.Hp; base += rpp - 1, ++pass) {
+            const int pr = base + lr;
+            const bool live = lr < rpp && pr < p.Hp;
+            const int ra = 2 * pr, xa = 2 * px;
+            const bool rbok = live && ra + 1 < p.H, xbok = xa + 1 < p.W;
+            row_t rw[4];  // grid rows 2pr-1 .. 2pr+2 (zero outside the grid); shuffles need every lane
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                int rr = 2 * pr - 2 + q;
+            for (int q = 0; q < 4; ++q) {
+                int rr = ra - 1 + q;
                 row_t v = __shfl(myrow, rr & 63);
-                rw[q] = (rr >= 0 && rr < p.H) ? v : (row_t)0;
+                rw[q] = (live && rr >= 0 && rr < p.H) ? v : (row_t)0;
             }
+            float acc[4][STEM_C];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int o = 0; o < STEM_C; ++o) acc[j][o] = bias[o];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
+                const int x = xa + (j & 1);
+                const bool ok = live && ((j >> 1) ? rbok : true) && ((j & 1) ? xbok : true);
+                if (!ok) continue;
+                const row_t r0 = (j >> 1) ? rw[1] : rw[0], r1 = (j >> 1) ? rw[2] : rw[1], r2 = (j >> 1) ? rw[3] : rw[2];
+                u32 b0 = x ? (u32)((r0 >> (x - 1)) & 7) : (u32)((r0 << 1) & 7);
+                u32 b1 = x ? (u32)((r1 >> (x - 1)) & 7) : (u32)((r1 << 1) & 7);
+                u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
+                u32 pat = b0 | (b1 << 3) | (b2 << 6);
+                if (pat) {
+                    const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
+                }
+            }
+            for (int i = 0; i < p.N; ++i) {
+                if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
+                const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
+                const int iw = whi & 255, ih = whi >> 8;
+                const int rc0 = live ? stem_class(ra, ih) : -1, cc0 = stem_class(xa, iw);
+                if (__ballot(rc0 >= 0 && cc0 >= 0) == 0ull) continue;  // the item's rectangle (+1 border) misses every lane's block
+                if (rc0 < 0 || cc0 < 0) continue;
+                const int rc1 = rbok ? stem_class(ra + 1, ih) : -1, cc1 = xbok ? stem_class(xa + 1, iw) : -1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rc = (j >> 1) ? rc1 : rc0, cc = (j & 1) ? cc1 : cc0;
+                    if (rc < 0 || cc < 0) continue;
+                    const int trow = (i * 5 + rc) * 5 + cc;
+                    const float4 *tt = T_LDS ? (sT4 + trow * (STEM_C / 4)) : ((const float4 *)p.stemT + (size_t)trow * (STEM_C / 4));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
+                }
+            }
+            // max-pool: own block, then the right column of the left lane, the bottom row of the upper lane, the corner of the upper-left
+            const bool has_l = px > 0, has_u = lr > 0;
             float best[STEM_C];
 #pragma unroll
-            for (int o = 0; o < STEM_C; ++o) best[o] = -INFINITY;
-            for (int wr = 0; wr < 3; ++wr) {  // one row of the pooling window at a time: three convolution outputs per lane
-                const int r = 2 * pr - 1 + wr;
-                const bool rowok = live && r >= 0 && r < p.H;
-                float acc[3][STEM_C];
-#pragma unroll
-                for (int wx = 0; wx < 3; ++wx)
-#pragma unroll
-                    for (int o = 0; o < STEM_C; ++o) acc[wx][o] = bias[o];
-                const row_t r0 = wr == 0 ? rw[0] : (wr == 1 ? rw[1] : rw[2]), r1 = wr == 0 ? rw[1] : (wr == 1 ? rw[2] : rw[3]),
-                            r2 = wr == 0 ? rw[2] : (wr == 1 ? rw[3] : rw[4]);
-#pragma unroll
-                for (int wx = 0; wx < 3; ++wx) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
-                    const int x = 2 * px - 1 + wx;
-                    if (!(rowok && x >= 0 && x < p.W)) continue;
-                    u32 b0 = x ? (u32)((r0 >> (x - 1)) & 7) : (u32)((r0 << 1) & 7);
-                    u32 b1 = x ? (u32)((r1 >> (x - 1)) & 7) : (u32)((r1 << 1) & 7);
-                    u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
-                    u32 pat = b0 | (b1 << 3) | (b2 << 6);
-                    if (pat) {
-                        const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
-                    }
-                }
-                for (int i = 0; i < p.N; ++i) {
-                    if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
-                    const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
-                    const int iw = whi & 255, ih = whi >> 8;
-                    const int rc = rowok ? stem_class(r, ih) : -1;
-                    if (__ballot(rc >= 0) == 0ull) continue;  // no lane's row touches this item
-                    if (rc < 0) continue;
-                    const int trow = (i * 5 + rc) * 5;
-#pragma unroll
-                    for (int wx = 0; wx < 3; ++wx) {
-                        const int x = 2 * px - 1 + wx;
-                        const int cc = (x >= 0 && x < p.W) ? stem_class(x, iw) : -1;
-                        if (cc < 0) continue;
-                        const float4 *tt = T_LDS ? (sT4 + (trow + cc) * (STEM_C / 4)) : ((const float4 *)p.stemT + (size_t)(trow + cc) * (STEM_C / 4));
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[wx][4 * q] += v.x; acc[wx][4 * q + 1] += v.y; acc[wx][4 * q + 2] += v.z; acc[wx][4 * q + 3] += v.w; }
-                    }
-                }
-#pragma unroll
-                for (int wx = 0; wx < 3; ++wx) {
-                    const int x = 2 * px - 1 + wx;
-                    if (!(rowok && x >= 0 && x < p.W)) continue;
-#pragma unroll
-                    for (int o = 0; o < STEM_C; ++o) best[o] = fmaxf(best[o], acc[wx][o]);
-                }
+            for (int o = 0; o < STEM_C; ++o) {
+                const float v00 = live ? acc[0][o] : -INFINITY, v01 = (live && xbok) ? acc[1][o] : -INFINITY;
+                const float v10 = rbok ? acc[2][o] : -INFINITY, v11 = (rbok && xbok) ? acc[3][o] : -INFINITY;
+                const float fl = __shfl(fmaxf(v01, v11), (lane - 1) & 63);
+                const float fu = __shfl(fmaxf(v10, v11), (lane - p.Wp) & 63);
+                const float fc = __shfl(v11, (lane - p.Wp - 1) & 63);
+                float m = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+                if (has_l) m = fmaxf(m, fl);
+                if (has_u) m = fmaxf(m, fu);
+                if (has_l && has_u) m = fmaxf(m, fc);
+                best[o] = m;
             }
-            if (live && nhwc) {  // channels-last: a pixel's 16 channels are contiguous -> four 16-byte stores per lane
+            const bool store = live && (pass == 0 || lr > 0);
+            const int pp = pr * p.Wp + px;
+            if (store && nhwc) {  // channels-last: a pixel's 16 channels are contiguous -> four 16-byte stores per lane
                 float4 *o4 = (float4 *)(ob + (size_t)pp * STEM_C);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o4[q] = make_float4(best[4 * q], best[4 * q + 1], best[4 * q + 2], best[4 * q + 3]);
@@ -1207,7 +1217,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) r4[q] = make_float4(fmaxf(best[4 * q], 0.f), fmaxf(best[4 * q + 1], 0.f), fmaxf(best[4 * q + 2], 0.f), fmaxf(best[4 * q + 3], 0.f));
                 }
-            } else if (live) {
+            } else if (store) {
 #pragma unroll
                 for (int o = 0; o < STEM_C; ++o) ob[(size_t)o * P + pp] = best[o];
                 if (out_relu) {
@@ -1643,6 +1653,34 @@ __global__ void k_nn_bias_pool_nhwc(const float *x, const float *bias, float *ou
     }
     out[i] = m;
     if (out_relu) out_relu[i] = m > 0.f ? m : 0.f;
+}
+// Same for C % 4 == 0 and < 2^32 output quads: four channels per thread (16-byte loads and stores), 32-bit index arithmetic,
+// the bias added once after the maximum (x -> fl(x + b) is monotone, so max(fl(x_i + b)) == fl(max(x_i) + b) exactly).
+__global__ void __launch_bounds__(256) k_nn_bias_pool_nhwc4(const float4 *__restrict__ x, const float4 *__restrict__ bias, float4 *__restrict__ out,
+                                                          float4 *__restrict__ out_relu, unsigned n_quads, unsigned C4, int H, int W, int Hp, int Wp) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_quads) return;
+    const unsigned ch = i % C4, q = i / C4;
+    const unsigned px = q % (unsigned)Wp, q2 = q / (unsigned)Wp;
+    const unsigned pr = q2 % (unsigned)Hp, b = q2 / (unsigned)Hp;
+    const float4 *xb = x + (size_t)b * (unsigned)(H * W) * C4 + ch;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+        const int r = 2 * (int)pr + dr;
+        if (r < 0 || r >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int c = 2 * (int)px + dx;
+            if (c < 0 || c >= W) continue;
+            const float4 v = xb[(unsigned)(r * W + c) * C4];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    const float4 bi = bias[ch];
+    m.x += bi.x; m.y += bi.y; m.z += bi.z; m.w += bi.w;
+    out[i] = m;
+    if (out_relu) out_relu[i] = make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2229,7 +2267,10 @@ extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bia
     int Hp = (H + 1) / 2, Wp = (W + 1) / 2;
     long long n = (long long)B * C * Hp * Wp;
     if (n == 0) return RP_OK;
-    if (channels_last)
+    if (channels_last && C % 4 == 0 && n / 4 < 0xFFFFFF00LL)
+        hipLaunchKernelGGL(k_nn_bias_pool_nhwc4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, (const float4 *)x_dev, (const float4 *)bias_dev,
+                           (float4 *)out_dev, (float4 *)out_relu_dev, (unsigned)(n / 4), (unsigned)(C / 4), (int)H, (int)W, Hp, Wp);
+    else if (channels_last)
         hipLaunchKernelGGL(k_nn_bias_pool_nhwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C,
                            (int)H, (int)W, Hp, Wp);
     else

@@ -187,6 +187,45 @@ def test_engine_stem_matches_conv_and_pool(name):
     eng.close()
 
 
+@pytest.mark.parametrize("W,H,N", [(50, 50, 128), (33, 27, 40), (64, 9, 12), (7, 40, 48)])
+def test_engine_stem_other_shapes(W, H, N):
+    """The stem kernel's pass structure (several passes with a halo row, odd sizes, table in LDS or in L2) against conv + pool
+    with random first-layer weights, on leaves of searches driven by a uniform evaluator."""
+    import torch
+    import torch.nn.functional as F
+    from resource_packing_self_play_amd import _lib
+    from test_gpu_mcts import gen_items
+    games = 32
+    rng = np.random.default_rng(W * 100 + N)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+    torch.manual_seed(W + H + N)
+    conv = torch.nn.Conv2d(N + 1, 16, 3, padding=1).cuda()
+    eng = _lib.Engine(W, H, N, games, 6, move_rule=_lib.MOVE_SAMPLE, seed=5, edge_cap=600_000, stream=torch.cuda.current_stream().cuda_stream)
+    eng.stem_set_weights(conv.weight.detach().contiguous().data_ptr(), conv.bias.detach().contiguous().data_ptr())
+    eng.begin_episodes(wh, np.full(games, W * H, np.int32))
+    A = W * N
+    pi = torch.full((games, A), 1.0 / A, device="cuda"); v = torch.zeros(games, device="cuda")
+    planes = torch.zeros((games, N + 1, H, W), device="cuda"); stem = torch.zeros((games, 16, (H + 1) // 2, (W + 1) // 2), device="cuda")
+    stem_cl = torch.zeros_like(stem).contiguous(memory_format=torch.channels_last); stem_cl_relu = torch.zeros_like(stem_cl)
+    worst, checked = 0.0, 0
+    for step in range(40):
+        n = eng.search_step()
+        if n != games:
+            if n:
+                eng.commit_eval_host(pi[:n].cpu().numpy(), v[:n].cpu().numpy())
+            continue
+        checked += 1
+        eng.leaf_planes(planes.data_ptr(), games); eng.leaf_stem(stem.data_ptr(), games)
+        eng.leaf_stem(stem_cl.data_ptr(), games, stem_cl_relu.data_ptr(), channels_last=True)
+        with torch.no_grad():
+            want = F.max_pool2d(conv(planes), kernel_size=3, stride=2, padding=1)
+        worst = max(worst, float((stem - want).abs().max()))
+        assert torch.equal(stem_cl, stem) and torch.equal(stem_cl_relu, torch.relu(stem))
+        eng.commit_eval(pi.data_ptr(), v.data_ptr())
+    assert checked >= 10 and worst <= 2e-5, (checked, worst)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["c2_seed0", "c3_seed0"])
 def test_fused_elementwise_forward_matches_plain_forward(name):
     """forward_from_stem_fused (bias+ReLU, bias+skip, bias+pool through the engine's kernels) against forward_from_stem:
