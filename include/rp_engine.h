@@ -185,6 +185,11 @@ int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), 
 int rp_nn_pack_conv16(rp_ctx *ctx, const float *w_dev, float *frag_dev);
 int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, const float *bias0_dev, const float *frag1_dev, const float *bias1_dev,
                      float *out_dev, float *out_relu_dev /* may be NULL */, int64_t B, int32_t H, int32_t W);
+/* Both residual blocks of a 16-channel stage (ConvSequence.res_block0 then res_block1, BinpackingNNet.py:41-46) in one launch for
+ * images of at most 128 pixels: frag4 = [4][36][64] fragments and bias4 = [4][16] in execution order (block 0 conv0, conv1,
+ * block 1 conv0, conv1).  out_relu_dev may be NULL. */
+int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
+                     int32_t H, int32_t W);
 int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
                         int64_t B, int32_t C, int32_t HW);

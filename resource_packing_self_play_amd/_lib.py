@@ -65,6 +65,7 @@ _SIGS = {
     "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64, _i32]),
     "rp_nn_pack_conv16": (C.c_int, [_vp, _vp, _vp]),
     "rp_nn_resblock16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rp_nn_resstage16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32]),
@@ -291,6 +292,14 @@ class Engine:
         self._ck(self.L.rp_nn_resblock16(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag0.data_ptr()), C.c_void_p(bias0.data_ptr()),
                                          C.c_void_p(frag1.data_ptr()), C.c_void_p(bias1.data_ptr()), C.c_void_p(out.data_ptr()),
                                          C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
+
+    def nn_resstage16(self, x, frag4, bias4, out, out_relu=None):
+        """Both residual blocks of a 16-channel stage on channels-last x [B, 16, H, W] (H * W <= 128) in one launch."""
+        B, Cc, H, W = x.shape
+        if Cc != 16 or self._bchw(x)[2] != 1 or H * W > 128:
+            raise ValueError("nn_resstage16 needs a channels-last [B, 16, H, W] tensor with H * W <= 128")
+        self._ck(self.L.rp_nn_resstage16(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
 
     def nn_bias_relu(self, x, bias):
         B, Cc, inner = self._bchw(x)

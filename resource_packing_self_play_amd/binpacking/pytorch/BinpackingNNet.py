@@ -119,8 +119,9 @@ class BinPackingNNet(nn.Module):
         return self._dense
 
     def refresh_frags(self, ops):
-        """MFMA B-fragment copies of the 16-channel stage's residual convolutions for the engine's fused block kernel
-        (rp_nn_resblock16); refreshed in place after weight updates."""
+        """MFMA B-fragment copies of the 16-channel stage's residual convolutions for the engine's fused kernels
+        (rp_nn_resblock16 per block, rp_nn_resstage16 for both blocks at once); refreshed in place after weight updates.
+        The four fragments of a stage are slices of one [4][36 * 64] buffer, next to a [4][16] copy of the biases."""
         if not hasattr(self, "_dense"):
             self._dense = {}
         keep = []
@@ -128,14 +129,21 @@ class BinPackingNNet(nn.Module):
             for si, stage in enumerate(self.conv_seqs):
                 if stage.conv.out_channels != 16:
                     continue
+                skey, bkey = "stagefrag:%d" % si, "stagebias:%d" % si
+                if skey not in self._dense:
+                    dev = stage.conv.weight.device
+                    self._dense[skey] = torch.empty(4 * 36 * 64, device=dev, dtype=torch.float32)
+                    self._dense[bkey] = torch.empty(4 * 16, device=dev, dtype=torch.float32)
+                k = 0
                 for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
                     for ci, conv in enumerate((blk.conv0, blk.conv1)):
                         key = "frag:%d:b%dc%d" % (si, bi, ci)
-                        if key not in self._dense:
-                            self._dense[key] = torch.empty(36 * 64, device=conv.weight.device, dtype=torch.float32)
+                        self._dense[key] = self._dense[skey][k * 2304:(k + 1) * 2304]
+                        self._dense[bkey][k * 16:(k + 1) * 16].copy_(conv.bias.detach())
                         w = conv.weight.detach().contiguous()  # plain [16][16][3][3] order whatever the parameter's format
                         keep.append(w)
                         ops.nn_pack_conv16(w, self._dense[key])
+                        k += 1
         return keep
 
     @staticmethod
@@ -169,6 +177,14 @@ class BinPackingNNet(nn.Module):
                 x = torch.empty((b, ch, (h + 1) // 2, (w + 1) // 2), device=c.device, dtype=c.dtype, memory_format=fmt)
                 xr = torch.empty_like(x)
                 ops.nn_bias_pool(c, stage.conv.bias, x, xr)
+            sf = getattr(self, "_dense", {}).get("stagefrag:%d" % si) if cl and self.use_resblock_kernel else None
+            if sf is not None and x.shape[2] * x.shape[3] <= 128:  # both blocks of the stage in one kernel on the FP32 matrix cores
+                last = si == len(self.conv_seqs) - 1
+                out = torch.empty_like(x)
+                out_r = torch.empty_like(x) if last else None  # only the flatten -> ReLU -> hidden_fc path reads relu(out)
+                ops.nn_resstage16(x, sf, self._dense["stagebias:%d" % si], out, out_r)
+                x, xr = out, out_r
+                continue
             for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
                 f0 = getattr(self, "_dense", {}).get("frag:%d:b%dc0" % (si, bi)) if cl and self.use_resblock_kernel else None
                 if f0 is not None:  # whole block in one kernel on the FP32 matrix cores

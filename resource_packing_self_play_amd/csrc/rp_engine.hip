@@ -1798,6 +1798,103 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
     }
 }
 
+// Both residual blocks of the 16-channel stage in one kernel (ConvSequence.res_block0 / res_block1, BinpackingNNet.py:41-46):
+// four 3x3 convolutions back to back on ONE zero-bordered LDS image per wave.  All NT pixel tiles of the image keep their
+// accumulators in registers, so a convolution's output overwrites its own input image once its last fragment has been read;
+// the first block's output y1 stays in registers as the second block's skip operand.  Per leaf HBM sees one read of x (plus
+// an L2-hot re-read in accumulator layout) and one write of the result -- the intermediate block output, its ReLU copy and the
+// second kernel's launch tail are gone.  B fragments (36 VGPRs) are re-read from L2 per convolution to leave room for 3 waves
+// per SIMD.  frag = [4][36][64], bias = [4][16] in execution order (b0c0, b0c1, b1c0, b1c1).
+template <int NT>
+__device__ __forceinline__ void rs_conv(const float *img, const float *__restrict__ frag, int PW, const int (&abase)[NT], f32x4 (&acc)[NT]) {
+    const int lane = lane_id();
+    float bf[36];
+#pragma unroll
+    for (int s = 0; s < 36; ++s) bf[s] = frag[s * 64 + lane];
+    float a_cur[NT], a_nxt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+        if (s + 1 < 36) {
+            const int tap = (s + 1) >> 2, dr = tap / 3, dx = tap - 3 * dr;
+            const int off = (dr * PW + dx) * RB_STRIDE + 4 * ((s + 1) & 3);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], bf[s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    }
+}
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
+                                                       float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w) {
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE;
+    int *ptab = (int *)rb_lds;  // [PIX] padded LDS offset of every pixel's channel 0 (shared by the block)
+    float *img = rb_lds + ((PIX + 3) & ~3) + (size_t)wv * IMG;
+    for (int i = threadIdx.x; i < PIX; i += blockDim.x) { int r = i / S_w, c = i - r * S_w; ptab[i] = ((r + 1) * PW + c + 1) * RB_STRIDE; }
+    for (int i = lane; i < IMG; i += 64) img[i] = 0.f;  // the border stays zero
+    __syncthreads();
+    const long long leaf = (long long)blockIdx.x * 4 + wv;
+    if (leaf >= B) return;
+    const float *xl = x + (size_t)leaf * PIX * 16;
+    float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
+    for (int e4 = lane; e4 < PIX * 4; e4 += 64) {  // relu(x) into the padded image, 16 bytes per lane
+        float4 v = ((const float4 *)xl)[e4];
+        float *d = img + ptab[e4 >> 2] + 4 * (e4 & 3);
+        d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
+    }
+    int abase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int m = t * 16 + (lane & 15);
+        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+    }
+    const int c = lane & 15;
+    const float b0 = bias[c], b1 = bias[16 + c], b2 = bias[32 + c], b3 = bias[48 + c];
+    f32x4 acc[NT], y1[NT];
+    wave_sync();
+    rs_conv<NT>(img, frag, PW, abase, acc);                       // block 0, conv0
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < PIX) img[ptab[m] + c] = fmaxf(acc[t][q] + b0, 0.f); }
+    wave_sync();
+    rs_conv<NT>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int m = t * 16 + (lane >> 4) * 4 + q;
+            float y = 0.f;
+            if (m < PIX) { y = (acc[t][q] + b1) + xl[m * 16 + c]; img[ptab[m] + c] = fmaxf(y, 0.f); }
+            y1[t][q] = y;
+        }
+    wave_sync();
+    rs_conv<NT>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < PIX) img[ptab[m] + c] = fmaxf(acc[t][q] + b2, 0.f); }
+    wave_sync();
+    rs_conv<NT>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int m = t * 16 + (lane >> 4) * 4 + q;
+            if (m < PIX) {
+                float y = (acc[t][q] + b3) + y1[t][q];
+                ol[m * 16 + c] = y;
+                if (orl) orl[m * 16 + c] = fmaxf(y, 0.f);
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2299,6 +2396,28 @@ extern "C" int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *fr
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resblock16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_resblock16, dim3(grid), dim3(256), lds, ctx->stream, x_dev, frag0_dev, bias0_dev, frag1_dev, bias1_dev, out_dev, out_relu_dev, (long long)B,
                        (int)H, (int)W);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
+                                int32_t H, int32_t W) {
+    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 128)
+        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: bad argument (images of at most 128 pixels)");
+    if (B == 0) return RP_OK;
+    const size_t lds = ((size_t)4 * (H + 2) * (W + 2) * RB_STRIDE + (((size_t)H * W + 3) & ~(size_t)3)) * sizeof(float);
+    const int nt = (H * W + 15) / 16;
+    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define RS_LAUNCH(NT_)                                                                                                                              \
+    case NT_:                                                                                                                                       \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W); \
+        break;
+    switch (nt) {
+        RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
+        default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: unsupported image size");
+    }
+#undef RS_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }

@@ -28,6 +28,11 @@ for B in (2731, 4096, 10923):
         c1 = F.conv2d(c0, w1, None, padding=1); eng.nn_bias_residual(c1, b1, x, out, out_r)
     def fused_form():
         eng.nn_resblock16(x, f0, b0, f1, b1, out, out_r)
+    f4 = torch.cat([f0, f1, f0, f1]); b4 = torch.cat([b0, b1, b0, b1])
+    def stage_form():
+        eng.nn_resstage16(x, f4, b4, out, None)
+    t_c = timeit(stage_form)
+    print(f"B={B}: rp_nn_resstage16 (two blocks) {t_c:.0f} us ({2*2*2*B*16*16*9*100/t_c/1e6:.1f} TF)", flush=True)
     t_a = timeit(miopen_form); t_b = timeit(fused_form)
     fl = 2 * 2 * B * 16 * 16 * 9 * 100
     print(f"B={B}: MIOpen+fused-elementwise {t_a:.0f} us ({fl/t_a/1e6:.1f} TF)   rp_nn_resblock16 {t_b:.0f} us ({fl/t_b/1e6:.1f} TF)", flush=True)

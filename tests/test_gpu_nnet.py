@@ -314,3 +314,41 @@ def test_fused_resblock16_kernel_matches_pytorch_block():
     assert dpi <= 1e-6 and dv <= 1e-5
     net.nnet._dense.clear()
     eng.close()
+
+
+def test_fused_resstage16_kernel_matches_pytorch_blocks():
+    """rp_nn_resstage16 (both residual blocks of the 16-channel stage: four 3x3 convolutions in place on one LDS image) against
+    the module's two blocks through PyTorch, for every tile count the kernel is instantiated for."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    d = np.load(os.path.join(GOLDEN, "nnet_c3_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    eng = _lib.Engine(20, 20, 32, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(4)
+    st = net.nnet.conv_seqs[0]
+    net.refresh_fused(); keep = net.nnet.refresh_frags(eng)
+    frag4, bias4 = net.nnet._dense["stagefrag:0"], net.nnet._dense["stagebias:0"]
+    for (B, H, W) in [(5, 10, 10), (1030, 10, 10), (64, 7, 9), (33, 3, 3), (17, 8, 8), (9, 5, 5), (3, 1, 1), (21, 11, 11), (6, 8, 16), (7, 5, 13)]:
+        x = torch.randn(B, 16, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            want = st.res_block1(st.res_block0(x))
+        out, out_r = torch.empty_like(x), torch.empty_like(x)
+        eng.nn_resstage16(x, frag4, bias4, out, out_r)
+        out2 = torch.empty_like(x)
+        eng.nn_resstage16(x, frag4, bias4, out2, None)
+        torch.cuda.synchronize()
+        err = float((out - want).abs().max())
+        print("resstage16 B=%d %dx%d: max |delta| %.3e" % (B, H, W, err))
+        assert err <= 4e-5 and torch.equal(out_r, torch.relu(out)) and torch.equal(out2, out)
+    # and the whole evaluator through it
+    y = torch.randn(300, 16, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
+    net.nnet._dense.clear()
+    pi_a, v_a = net.predict_from_stem(y)
+    net.refresh_fused(); keep = net.nnet.refresh_frags(eng)
+    pi_b, v_b = net.predict_from_stem(y, torch.relu(y), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max())
+    print("evaluator with the stage kernel vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-5
+    net.nnet._dense.clear()
+    eng.close()
