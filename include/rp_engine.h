@@ -190,6 +190,12 @@ int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, co
  * block 1 conv0, conv1).  out_relu_dev may be NULL. */
 int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                      int32_t H, int32_t W);
+/* The same for a 32-channel stage on images of at most 80 pixels (5x5 at the 20x20 board).  rp_nn_pack_conv32 reorders a
+ * contiguous [32][32][3][3] weight into the kernel's streaming B-fragment order ([36][64][4] floats); frag4 = four of those,
+ * bias4 = [4][32], in execution order. */
+int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev);
+int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
+                     int32_t H, int32_t W);
 int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
                         int64_t B, int32_t C, int32_t HW);

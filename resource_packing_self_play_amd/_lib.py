@@ -66,6 +66,8 @@ _SIGS = {
     "rp_nn_pack_conv16": (C.c_int, [_vp, _vp, _vp]),
     "rp_nn_resblock16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_resstage16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "rp_nn_pack_conv32": (C.c_int, [_vp, _vp, _vp]),
+    "rp_nn_resstage32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32]),
@@ -299,6 +301,18 @@ class Engine:
         if Cc != 16 or self._bchw(x)[2] != 1 or H * W > 128:
             raise ValueError("nn_resstage16 needs a channels-last [B, 16, H, W] tensor with H * W <= 128")
         self._ck(self.L.rp_nn_resstage16(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
+
+    def nn_pack_conv32(self, weight, frag):
+        """weight: contiguous float32 [32, 32, 3, 3]; frag: float32 [36 * 64 * 4] buffer to fill (streaming B-fragment order)."""
+        self._ck(self.L.rp_nn_pack_conv32(self.h, C.c_void_p(weight.data_ptr()), C.c_void_p(frag.data_ptr())))
+
+    def nn_resstage32(self, x, frag4, bias4, out, out_relu=None):
+        """Both residual blocks of a 32-channel stage on channels-last x [B, 32, H, W] (H * W <= 80) in one launch."""
+        B, Cc, H, W = x.shape
+        if Cc != 32 or self._bchw(x)[2] != 1 or H * W > 80:
+            raise ValueError("nn_resstage32 needs a channels-last [B, 32, H, W] tensor with H * W <= 80")
+        self._ck(self.L.rp_nn_resstage32(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()),
                                          C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
 
     def nn_bias_relu(self, x, bias):

@@ -119,30 +119,34 @@ class BinPackingNNet(nn.Module):
         return self._dense
 
     def refresh_frags(self, ops):
-        """MFMA B-fragment copies of the 16-channel stage's residual convolutions for the engine's fused kernels
-        (rp_nn_resblock16 per block, rp_nn_resstage16 for both blocks at once); refreshed in place after weight updates.
-        The four fragments of a stage are slices of one [4][36 * 64] buffer, next to a [4][16] copy of the biases."""
+        """MFMA B-fragment copies of the residual convolutions for the engine's fused stage kernels (rp_nn_resstage16 for
+        16-channel stages on <= 128-pixel images, rp_nn_resstage32 for 32-channel stages on <= 80-pixel images; rp_nn_resblock16
+        takes single 16-channel blocks); refreshed in place after weight updates.  The four fragments of a stage are slices
+        of one buffer, next to a [4][C] copy of the biases, both in execution order."""
         if not hasattr(self, "_dense"):
             self._dense = {}
         keep = []
+        shapes = stage_shapes(self.in_channels, self.board_h, self.board_w)
         with torch.no_grad():
             for si, stage in enumerate(self.conv_seqs):
-                if stage.conv.out_channels != 16:
+                ch, h, w = shapes[si]
+                if not ((ch == 16 and h * w <= 128) or (ch == 32 and h * w <= 80)):
                     continue
+                n = 36 * 64 * (ch // 16) ** 2
                 skey, bkey = "stagefrag:%d" % si, "stagebias:%d" % si
                 if skey not in self._dense:
                     dev = stage.conv.weight.device
-                    self._dense[skey] = torch.empty(4 * 36 * 64, device=dev, dtype=torch.float32)
-                    self._dense[bkey] = torch.empty(4 * 16, device=dev, dtype=torch.float32)
+                    self._dense[skey] = torch.empty(4 * n, device=dev, dtype=torch.float32)
+                    self._dense[bkey] = torch.empty(4 * ch, device=dev, dtype=torch.float32)
                 k = 0
                 for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
                     for ci, conv in enumerate((blk.conv0, blk.conv1)):
                         key = "frag:%d:b%dc%d" % (si, bi, ci)
-                        self._dense[key] = self._dense[skey][k * 2304:(k + 1) * 2304]
-                        self._dense[bkey][k * 16:(k + 1) * 16].copy_(conv.bias.detach())
-                        w = conv.weight.detach().contiguous()  # plain [16][16][3][3] order whatever the parameter's format
-                        keep.append(w)
-                        ops.nn_pack_conv16(w, self._dense[key])
+                        self._dense[key] = self._dense[skey][k * n:(k + 1) * n]
+                        self._dense[bkey][k * ch:(k + 1) * ch].copy_(conv.bias.detach())
+                        wt = conv.weight.detach().contiguous()  # plain [C][C][3][3] order whatever the parameter's format
+                        keep.append(wt)
+                        (ops.nn_pack_conv16 if ch == 16 else ops.nn_pack_conv32)(wt, self._dense[key])
                         k += 1
         return keep
 
@@ -178,15 +182,15 @@ class BinPackingNNet(nn.Module):
                 xr = torch.empty_like(x)
                 ops.nn_bias_pool(c, stage.conv.bias, x, xr)
             sf = getattr(self, "_dense", {}).get("stagefrag:%d" % si) if cl and self.use_resblock_kernel else None
-            if sf is not None and x.shape[2] * x.shape[3] <= 128:  # both blocks of the stage in one kernel on the FP32 matrix cores
+            if sf is not None:  # both blocks of the stage in one kernel on the FP32 matrix cores
                 last = si == len(self.conv_seqs) - 1
                 out = torch.empty_like(x)
                 out_r = torch.empty_like(x) if last else None  # only the flatten -> ReLU -> hidden_fc path reads relu(out)
-                ops.nn_resstage16(x, sf, self._dense["stagebias:%d" % si], out, out_r)
+                (ops.nn_resstage16 if x.shape[1] == 16 else ops.nn_resstage32)(x, sf, self._dense["stagebias:%d" % si], out, out_r)
                 x, xr = out, out_r
                 continue
             for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
-                f0 = getattr(self, "_dense", {}).get("frag:%d:b%dc0" % (si, bi)) if cl and self.use_resblock_kernel else None
+                f0 = getattr(self, "_dense", {}).get("frag:%d:b%dc0" % (si, bi)) if cl and self.use_resblock_kernel and x.shape[1] == 16 else None
                 if f0 is not None:  # whole block in one kernel on the FP32 matrix cores
                     out, out_r = torch.empty_like(x), torch.empty_like(x)
                     ops.nn_resblock16(x, f0, blk.conv0.bias, self._dense["frag:%d:b%dc1" % (si, bi)], blk.conv1.bias, out, out_r)

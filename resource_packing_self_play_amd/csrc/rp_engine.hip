@@ -1895,6 +1895,144 @@ __global__ void __launch_bounds__(256, 2) k_resstage16(const float *__restrict__
         }
 }
 
+// The same for a 32-channel stage on small images (5x5 at the 20x20 board): M = the pixels of IMGW consecutive leaves (75 of
+// 80 rows at 3 x 25), N = 2 tiles of 16 output channels, K = 9 taps x 32 channels = 72 k-steps.  The B operand no longer
+// fits in registers (144 fragments per convolution), so it streams from L2 -- one 16-byte load per lane per two k-steps
+// ([36][64] float4 = {s even: n-tile 0, 1; s odd: n-tile 0, 1}), prefetched two loads ahead of the 20 MFMAs that consume it.
+// Pixel stride 33 floats keeps the per-k-step A reads (16 pixels x 2 channels per half-wave) on distinct banks.
+#define R32_STRIDE 33
+// fragment order of a [32][32][3][3] weight: s = k-step (tap = s >> 3, ci = 4 * (s & 7) + (lane >> 4)), co = 16 * nt + (lane & 15)
+__global__ void k_pack_conv32(const float *w, float *fragq) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 36 * 64 * 4) return;
+    int e = i & 3, l = (i >> 2) & 63, s2 = i >> 8;
+    int s = 2 * s2 + (e >> 1), nt = e & 1;
+    int co = 16 * nt + (l & 15), ci = 4 * (s & 7) + (l >> 4), tap = s >> 3;
+    fragq[i] = w[(co * 32 + ci) * 9 + tap];
+}
+template <int NT>
+__device__ __forceinline__ void r32_conv(const float *img, const float4 *__restrict__ fragq, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2]) {
+    const int lane = lane_id();
+    float4 bq[3];
+    bq[0] = fragq[lane]; bq[1] = fragq[64 + lane];
+    float a_cur[NT], a_nxt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
+#pragma unroll
+    for (int s2 = 0; s2 < 36; ++s2) {
+        if (s2 + 2 < 36) bq[(s2 + 2) % 3] = fragq[(s2 + 2) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s = 2 * s2 + j;
+            if (s + 1 < 72) {
+                const int tap = (s + 1) >> 3, dr = tap / 3, dx = tap - 3 * dr;
+                const int off = (dr * PW + dx) * R32_STRIDE + 4 * ((s + 1) & 7);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
+            }
+            const float b0 = j ? bq[s2 % 3].z : bq[s2 % 3].x, b1 = j ? bq[s2 % 3].w : bq[s2 % 3].y;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b1, acc[t][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+        }
+    }
+}
+// frag = [4][36][64] float4, bias = [4][32] in execution order; IMGW leaves per wave, IMGW * PIX <= 16 * NT.
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
+                                                       float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW) {
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * R32_STRIDE, MP = IMGW * PIX;
+    int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
+    float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
+    for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+        int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
+        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * R32_STRIDE : 0;
+    }
+    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;  // borders (and missing leaves of the last group) stay zero
+    __syncthreads();
+    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    if (leaf0 >= B) return;
+    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
+    const float *xl = x + (size_t)leaf0 * PIX * 32;
+    float *ol = out + (size_t)leaf0 * PIX * 32, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 32 : nullptr;
+    for (int e4 = lane; e4 < npix * 8; e4 += 64) {  // relu(x) into the padded images
+        float4 v = ((const float4 *)xl)[e4];
+        float *d = img + ptab[e4 >> 3] + 4 * (e4 & 7);
+        d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
+    }
+    int abase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int m = t * 16 + (lane & 15);
+        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * R32_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+    }
+    const int c = lane & 15;
+    f32x4 acc[NT][2], y1[NT][2];
+    wave_sync();
+    r32_conv<NT>(img, frag, PW, abase, acc);                       // block 0, conv0
+    {
+        const float ba = bias[c], bb = bias[16 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = t * 16 + (lane >> 4) * 4 + q;
+                if (m < npix) { float *d = img + ptab[m] + c; d[0] = fmaxf(acc[t][0][q] + ba, 0.f); d[16] = fmaxf(acc[t][1][q] + bb, 0.f); }
+            }
+    }
+    wave_sync();
+    r32_conv<NT>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
+    {
+        const float ba = bias[32 + c], bb = bias[48 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = t * 16 + (lane >> 4) * 4 + q;
+                float ya = 0.f, yb = 0.f;
+                if (m < npix) {
+                    ya = (acc[t][0][q] + ba) + xl[m * 32 + c]; yb = (acc[t][1][q] + bb) + xl[m * 32 + 16 + c];
+                    float *d = img + ptab[m] + c; d[0] = fmaxf(ya, 0.f); d[16] = fmaxf(yb, 0.f);
+                }
+                y1[t][0][q] = ya; y1[t][1][q] = yb;
+            }
+    }
+    wave_sync();
+    r32_conv<NT>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
+    {
+        const float ba = bias[64 + c], bb = bias[80 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = t * 16 + (lane >> 4) * 4 + q;
+                if (m < npix) { float *d = img + ptab[m] + c; d[0] = fmaxf(acc[t][0][q] + ba, 0.f); d[16] = fmaxf(acc[t][1][q] + bb, 0.f); }
+            }
+    }
+    wave_sync();
+    r32_conv<NT>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
+    {
+        const float ba = bias[96 + c], bb = bias[112 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = t * 16 + (lane >> 4) * 4 + q;
+                if (m < npix) {
+                    float ya = (acc[t][0][q] + ba) + y1[t][0][q], yb = (acc[t][1][q] + bb) + y1[t][1][q];
+                    ol[m * 32 + c] = ya; ol[m * 32 + 16 + c] = yb;
+                    if (orl) { orl[m * 32 + c] = fmaxf(ya, 0.f); orl[m * 32 + 16 + c] = fmaxf(yb, 0.f); }
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -2416,6 +2554,42 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
         default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: unsupported image size");
+    }
+#undef RS_LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev) {
+    if (!ctx || !w_dev || !frag_dev) return fail(ctx, RP_ERR_ARG, "rp_nn_pack_conv32: bad argument");
+    hipLaunchKernelGGL(k_pack_conv32, dim3(36), dim3(256), 0, ctx->stream, w_dev, frag_dev);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
+                                int32_t H, int32_t W) {
+    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 80)
+        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: bad argument (images of at most 80 pixels)");
+    if (B == 0) return RP_OK;
+    const int PIX = H * W;
+    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * R32_STRIDE * sizeof(float);
+    int imgw = 80 / PIX;                                              // leaves per wave: at most 5 pixel tiles of 16
+    while (imgw > 1 && 4 * imgw * img_bytes + 320 > 78 * 1024) --imgw;  // two workgroups per CU
+    const int nt = (imgw * PIX + 15) / 16;
+    const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * imgw * img_bytes;
+    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: %dx%d image does not fit LDS", H, W);
+    const long long tasks = (B + imgw - 1) / imgw;
+    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+#define RS_LAUNCH(NT_)                                                                                                                              \
+    case NT_:                                                                                                                                       \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage32<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(k_resstage32<NT_>, grid, block, lds, ctx->stream, x_dev, (const float4 *)frag4_dev, bias4_dev, out_dev, out_relu_dev,    \
+                           (long long)B, (int)H, (int)W, imgw);                                                                                     \
+        break;
+    switch (nt) {
+        RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5)
+        default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: unsupported image size");
     }
 #undef RS_LAUNCH
     HIPCHK(ctx, hipGetLastError());

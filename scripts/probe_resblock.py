@@ -36,3 +36,13 @@ for B in (2731, 4096, 10923):
     t_a = timeit(miopen_form); t_b = timeit(fused_form)
     fl = 2 * 2 * B * 16 * 16 * 9 * 100
     print(f"B={B}: MIOpen+fused-elementwise {t_a:.0f} us ({fl/t_a/1e6:.1f} TF)   rp_nn_resblock16 {t_b:.0f} us ({fl/t_b/1e6:.1f} TF)", flush=True)
+
+for (B, H) in ((10923, 5), (10923, 3)):
+    x = torch.randn(B, 32, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    ws = [torch.randn(32, 32, 3, 3, device="cuda") * 0.05 for _ in range(4)]
+    f4 = torch.empty(4 * 36 * 64 * 4, device="cuda"); b4 = torch.randn(128, device="cuda")
+    for k, w in enumerate(ws):
+        eng.nn_pack_conv32(w, f4[k * 9216:(k + 1) * 9216])
+    out = torch.empty_like(x)
+    t = timeit(lambda: eng.nn_resstage32(x, f4, b4, out, None))
+    print(f"B={B} {H}x{H}x32: rp_nn_resstage32 (two blocks) {t:.0f} us ({4*2*B*32*32*9*H*H/t/1e6:.1f} TF)", flush=True)

@@ -352,3 +352,42 @@ def test_fused_resstage16_kernel_matches_pytorch_blocks():
     assert dpi <= 1e-6 and dv <= 1e-5
     net.nnet._dense.clear()
     eng.close()
+
+
+def test_fused_resstage32_kernel_matches_pytorch_blocks():
+    """rp_nn_resstage32 (both residual blocks of a 32-channel stage, several leaves per wave, weights streamed from L2) against
+    the module's two blocks through PyTorch, for group sizes that do and do not divide the batch."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    d = np.load(os.path.join(GOLDEN, "nnet_c3_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    eng = _lib.Engine(20, 20, 32, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(5)
+    net.refresh_fused(); keep = net.nnet.refresh_frags(eng)
+    for si in (1, 2):
+        st = net.nnet.conv_seqs[si]
+        frag4, bias4 = net.nnet._dense["stagefrag:%d" % si], net.nnet._dense["stagebias:%d" % si]
+        for (B, H, W) in [(5, 5, 5), (1030, 5, 5), (3001, 3, 3), (7, 3, 3), (64, 4, 4), (33, 2, 3), (3, 1, 1), (10, 8, 8), (11, 7, 9), (4, 8, 10), (13, 6, 6)]:
+            x = torch.randn(B, 32, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+            with torch.no_grad():
+                want = st.res_block1(st.res_block0(x))
+            out, out_r = torch.empty_like(x), torch.empty_like(x)
+            eng.nn_resstage32(x, frag4, bias4, out, out_r)
+            out2 = torch.empty_like(x)
+            eng.nn_resstage32(x, frag4, bias4, out2, None)
+            torch.cuda.synchronize()
+            err = float((out - want).abs().max())
+            print("resstage32 stage %d B=%d %dx%d: max |delta| %.3e" % (si, B, H, W, err))
+            assert err <= 4e-5 and torch.equal(out_r, torch.relu(out)) and torch.equal(out2, out)
+    # and the whole evaluator through the stage kernels
+    y = torch.randn(301, 16, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
+    net.nnet._dense.clear()
+    pi_a, v_a = net.predict_from_stem(y)
+    net.refresh_fused(); keep = net.nnet.refresh_frags(eng)
+    pi_b, v_b = net.predict_from_stem(y, torch.relu(y), ops=eng)
+    torch.cuda.synchronize()
+    dpi, dv = float((pi_a - pi_b).abs().max()), float((v_a - v_b).abs().max())
+    print("evaluator with the stage kernels vs plain: max |dpi| %.3e max |dv| %.3e" % (dpi, dv))
+    assert dpi <= 1e-6 and dv <= 1e-5
+    net.nnet._dense.clear()
+    eng.close()
