@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--event-every", type=int, default=16, help="take per-phase HIP-event timings every n-th wave")
+    ap.add_argument("--profile-waves", type=int, default=0, help="profiling aid: stop after this many waves per group and print no metric")
     ap.add_argument("--cpu-worker", default=None)
     ap.add_argument("--cpu-episodes", type=int, default=1)
     ap.add_argument("--cpu-seed", type=int, default=100)
@@ -230,6 +231,10 @@ def main():
                 waves += 1
             if sp.active() == 0:
                 break
+            if a.profile_waves and waves >= a.profile_waves:
+                torch.cuda.synchronize(dev)
+                print("profile run: stopped after %d waves per group" % waves, file=sys.stderr)
+                sys.exit(0)
         torch.cuda.synchronize(dev)
         for ev, _, _ in pending:
             phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]

@@ -191,11 +191,15 @@ int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, co
 int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                      int32_t H, int32_t W);
 /* The same for a 32-channel stage on images of at most 80 pixels (5x5 at the 20x20 board).  rp_nn_pack_conv32 reorders a
- * contiguous [32][32][3][3] weight into the kernel's streaming B-fragment order ([36][64][4] floats); frag4 = four of those,
- * bias4 = [4][32], in execution order. */
-int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev);
+ * contiguous [32][Cin][3][3] weight (Cin 16 or 32) into the kernels' streaming B-fragment order ([9 * Cin / 8][64][4] floats);
+ * frag4 = four of those (Cin 32), bias4 = [4][32], in execution order. */
+int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev, int32_t Cin);
 int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                      int32_t H, int32_t W);
+/* First convolution of a 32-channel stage + bias + max_pool2d(3, stride 2, pad 1) (ConvSequence.conv, BinpackingNNet.py:34,39-40)
+ * on channels-last x [B][H][W][Cin] -> out [B][(H+1)/2][(W+1)/2][32]; Cin 16 (<= 112 pixels) or 32 (<= 80 pixels). */
+int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *frag_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t Cin, int32_t H,
+                     int32_t W);
 int rp_nn_bias_relu(rp_ctx *ctx, float *x_dev, const float *bias_dev, int64_t B, int32_t C, int32_t HW);
 int rp_nn_bias_residual(rp_ctx *ctx, const float *x_dev, const float *bias_dev, const float *res_dev, float *out_dev, float *out_relu_dev,
                         int64_t B, int32_t C, int32_t HW);

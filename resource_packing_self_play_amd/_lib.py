@@ -66,7 +66,8 @@ _SIGS = {
     "rp_nn_pack_conv16": (C.c_int, [_vp, _vp, _vp]),
     "rp_nn_resblock16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_resstage16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
-    "rp_nn_pack_conv32": (C.c_int, [_vp, _vp, _vp]),
+    "rp_nn_pack_conv32": (C.c_int, [_vp, _vp, _vp, _i32]),
+    "rp_nn_convpool32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32]),
     "rp_nn_resstage32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_relu": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_bias_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
@@ -304,8 +305,17 @@ class Engine:
                                          C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
 
     def nn_pack_conv32(self, weight, frag):
-        """weight: contiguous float32 [32, 32, 3, 3]; frag: float32 [36 * 64 * 4] buffer to fill (streaming B-fragment order)."""
-        self._ck(self.L.rp_nn_pack_conv32(self.h, C.c_void_p(weight.data_ptr()), C.c_void_p(frag.data_ptr())))
+        """weight: contiguous float32 [32, Cin, 3, 3], Cin 16 or 32; frag: float32 [9 * Cin * 32] buffer to fill (streaming
+        B-fragment order)."""
+        self._ck(self.L.rp_nn_pack_conv32(self.h, C.c_void_p(weight.data_ptr()), C.c_void_p(frag.data_ptr()), int(weight.shape[1])))
+
+    def nn_convpool32(self, x, frag, bias, out):
+        """conv3x3(Cin -> 32) + bias + max_pool2d(3, 2, 1) on channels-last x [B, Cin, H, W] -> out [B, 32, (H+1)//2, (W+1)//2]."""
+        B, Cc, H, W = x.shape
+        if self._bchw(x)[2] != 1 or self._bchw(out)[2] != 1:
+            raise ValueError("nn_convpool32 needs channels-last tensors")
+        self._ck(self.L.rp_nn_convpool32(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), B, Cc, H, W))
 
     def nn_resstage32(self, x, frag4, bias4, out, out_relu=None):
         """Both residual blocks of a 32-channel stage on channels-last x [B, 32, H, W] (H * W <= 80) in one launch."""

@@ -148,6 +148,18 @@ class BinPackingNNet(nn.Module):
                         keep.append(wt)
                         (ops.nn_pack_conv16 if ch == 16 else ops.nn_pack_conv32)(wt, self._dense[key])
                         k += 1
+            for si, stage in enumerate(self.conv_seqs):  # first convolution (+ max-pool) of the 32-channel stages: rp_nn_convpool32
+                if si == 0 or shapes[si][0] != 32:
+                    continue
+                cin, h, w = shapes[si - 1]
+                if not ((cin == 16 and h * w <= 112) or (cin == 32 and h * w <= 80)):
+                    continue
+                key = "entryfrag:%d" % si
+                if key not in self._dense:
+                    self._dense[key] = torch.empty(9 * cin * 32, device=stage.conv.weight.device, dtype=torch.float32)
+                wt = stage.conv.weight.detach().contiguous()
+                keep.append(wt)
+                ops.nn_pack_conv32(wt, self._dense[key])
         return keep
 
     @staticmethod
@@ -175,7 +187,13 @@ class BinPackingNNet(nn.Module):
         fmt = torch.channels_last if cl else torch.contiguous_format
         x, xr = y, y_relu
         for si, stage in enumerate(self.conv_seqs):
-            if si > 0:
+            ef = getattr(self, "_dense", {}).get("entryfrag:%d" % si) if cl and self.use_resblock_kernel and si > 0 else None
+            if ef is not None:  # convolution + bias + max-pool in one kernel on the FP32 matrix cores
+                b, _, h, w = x.shape
+                xin, x = x, torch.empty((b, stage.conv.out_channels, (h + 1) // 2, (w + 1) // 2), device=x.device, dtype=x.dtype, memory_format=fmt)
+                ops.nn_convpool32(xin, ef, stage.conv.bias, x)
+                xr = None
+            elif si > 0:
                 c = F.conv2d(x, stage.conv.weight, None, padding=1)
                 b, ch, h, w = c.shape
                 x = torch.empty((b, ch, (h + 1) // 2, (w + 1) // 2), device=c.device, dtype=c.dtype, memory_format=fmt)
@@ -189,6 +207,8 @@ class BinPackingNNet(nn.Module):
                 (ops.nn_resstage16 if x.shape[1] == 16 else ops.nn_resstage32)(x, sf, self._dense["stagebias:%d" % si], out, out_r)
                 x, xr = out, out_r
                 continue
+            if xr is None:
+                xr = torch.relu(x)
             for bi, blk in enumerate((stage.res_block0, stage.res_block1)):
                 f0 = getattr(self, "_dense", {}).get("frag:%d:b%dc0" % (si, bi)) if cl and self.use_resblock_kernel and x.shape[1] == 16 else None
                 if f0 is not None:  # whole block in one kernel on the FP32 matrix cores

@@ -1901,17 +1901,21 @@ __global__ void __launch_bounds__(256, 2) k_resstage16(const float *__restrict__
 // ([36][64] float4 = {s even: n-tile 0, 1; s odd: n-tile 0, 1}), prefetched two loads ahead of the 20 MFMAs that consume it.
 // Pixel stride 33 floats keeps the per-k-step A reads (16 pixels x 2 channels per half-wave) on distinct banks.
 #define R32_STRIDE 33
-// fragment order of a [32][32][3][3] weight: s = k-step (tap = s >> 3, ci = 4 * (s & 7) + (lane >> 4)), co = 16 * nt + (lane & 15)
-__global__ void k_pack_conv32(const float *w, float *fragq) {
+// fragment order of a [32][Cin][3][3] weight (KS = Cin / 4 k-steps per tap): s = k-step (tap = s / KS, ci = 4 * (s % KS) + (lane >> 4)),
+// co = 16 * nt + (lane & 15); fragq[s / 2][lane] = {s even: n-tile 0, 1; s odd: n-tile 0, 1}
+__global__ void k_pack_conv32(const float *w, float *fragq, int Cin) {
+    const int KS = Cin / 4;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 36 * 64 * 4) return;
+    if (i >= 9 * KS * 64 * 2) return;
     int e = i & 3, l = (i >> 2) & 63, s2 = i >> 8;
     int s = 2 * s2 + (e >> 1), nt = e & 1;
-    int co = 16 * nt + (l & 15), ci = 4 * (s & 7) + (l >> 4), tap = s >> 3;
-    fragq[i] = w[(co * 32 + ci) * 9 + tap];
+    int co = 16 * nt + (l & 15), ci = 4 * (s % KS) + (l >> 4), tap = s / KS;
+    fragq[i] = w[(co * Cin + ci) * 9 + tap];
 }
-template <int NT>
+// One 3x3 convolution Cin = 4 * KS -> 32 channels over NT pixel tiles; image pixel stride 4 * KS + 1 floats.
+template <int NT, int KS>
 __device__ __forceinline__ void r32_conv(const float *img, const float4 *__restrict__ fragq, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2]) {
+    constexpr int NS = 9 * KS, STRIDE = 4 * KS + 1;
     const int lane = lane_id();
     float4 bq[3];
     bq[0] = fragq[lane]; bq[1] = fragq[64 + lane];
@@ -1919,14 +1923,14 @@ __device__ __forceinline__ void r32_conv(const float *img, const float4 *__restr
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
 #pragma unroll
-    for (int s2 = 0; s2 < 36; ++s2) {
-        if (s2 + 2 < 36) bq[(s2 + 2) % 3] = fragq[(s2 + 2) * 64 + lane];
+    for (int s2 = 0; s2 < NS / 2; ++s2) {
+        if (s2 + 2 < NS / 2) bq[(s2 + 2) % 3] = fragq[(s2 + 2) * 64 + lane];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int s = 2 * s2 + j;
-            if (s + 1 < 72) {
-                const int tap = (s + 1) >> 3, dr = tap / 3, dx = tap - 3 * dr;
-                const int off = (dr * PW + dx) * R32_STRIDE + 4 * ((s + 1) & 7);
+            if (s + 1 < NS) {
+                const int tap = (s + 1) / KS, dr = tap / 3, dx = tap - 3 * dr;
+                const int off = (dr * PW + dx) * STRIDE + 4 * ((s + 1) % KS);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
             }
@@ -1975,7 +1979,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
     const int c = lane & 15;
     f32x4 acc[NT][2], y1[NT][2];
     wave_sync();
-    r32_conv<NT>(img, frag, PW, abase, acc);                       // block 0, conv0
+    r32_conv<NT, 8>(img, frag, PW, abase, acc);                       // block 0, conv0
     {
         const float ba = bias[c], bb = bias[16 + c];
 #pragma unroll
@@ -1987,7 +1991,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
             }
     }
     wave_sync();
-    r32_conv<NT>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
+    r32_conv<NT, 8>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
     {
         const float ba = bias[32 + c], bb = bias[48 + c];
 #pragma unroll
@@ -2004,7 +2008,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
             }
     }
     wave_sync();
-    r32_conv<NT>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
+    r32_conv<NT, 8>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
     {
         const float ba = bias[64 + c], bb = bias[80 + c];
 #pragma unroll
@@ -2016,7 +2020,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
             }
     }
     wave_sync();
-    r32_conv<NT>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
+    r32_conv<NT, 8>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
     {
         const float ba = bias[96 + c], bb = bias[112 + c];
 #pragma unroll
@@ -2030,6 +2034,82 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
                     if (orl) { orl[m * 32 + c] = fmaxf(ya, 0.f); orl[m * 32 + 16 + c] = fmaxf(yb, 0.f); }
                 }
             }
+    }
+}
+
+// Entry of a 32-channel stage (ConvSequence.conv + max_pool2d(3, 2, 1), BinpackingNNet.py:34,39-40): 3x3 convolution
+// Cin = 4 * KS -> 32 channels over the pixels of IMGW consecutive leaves, bias, then the 3x3 / stride-2 max-pool out of an
+// LDS staging copy of the convolution output that overwrites the (fully consumed) input images.  Output: pooled x, channels-last.
+template <int NT, int KS>
+__global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
+                                                       float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats) {
+    constexpr int STRIDE = 4 * KS + 1, CIN = 4 * KS;
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * STRIDE, MP = IMGW * PIX;
+    int *ptab = (int *)rb_lds;
+    float *img = rb_lds + 16 * NT + ((IMGW * (((S_h + 1) >> 1) * ((S_w + 1) >> 1)) + 3) & ~3) + (size_t)wv * wave_floats;
+    for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+        int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
+        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * STRIDE : 0;
+    }
+    {
+        const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PPn = Hp * Wp;
+        for (int i = threadIdx.x; i < IMGW * PPn; i += blockDim.x) {
+            int im = i / PPn, pp = i - im * PPn, pr = pp / Wp, px = pp - pr * Wp;
+            ptab[16 * NT + i] = (im * PIX + 2 * pr * S_w + 2 * px) | ((pr > 0) << 16) | ((2 * pr + 1 < S_h) << 17) | ((px > 0) << 18) | ((2 * px + 1 < S_w) << 19);
+        }
+    }
+    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;
+    __syncthreads();
+    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    if (leaf0 >= B) return;
+    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
+    const float *xl = x + (size_t)leaf0 * PIX * CIN;
+    for (int e4 = lane; e4 < npix * KS; e4 += 64) {  // x (no ReLU in front of a stage's first convolution) into the padded images
+        float4 v = ((const float4 *)xl)[e4];
+        float *d = img + ptab[e4 / KS] + 4 * (e4 % KS);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    int abase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int m = t * 16 + (lane & 15);
+        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * STRIDE + (lane >> 4);
+    }
+    const int c = lane & 15;
+    f32x4 acc[NT][2];
+    wave_sync();
+    r32_conv<NT, KS>(img, frag, PW, abase, acc);
+    wave_sync();
+    {   // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows
+        const float ba = bias[c], bb = bias[16 + c];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int m = t * 16 + (lane >> 4) * 4 + q;
+                if (m < npix) { float *d = img + m * 36 + c; d[0] = acc[t][0][q] + ba; d[16] = acc[t][1][q] + bb; }
+            }
+    }
+    wave_sync();
+    // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table
+    const int PP = ((S_h + 1) >> 1) * ((S_w + 1) >> 1);
+    const int *pool = ptab + 16 * NT;  // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
+    float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
+    const int cq = lane & 7;
+    for (int pq = lane >> 3; pq < nimg * PP; pq += 8) {
+        const int info = pool[pq], ctr = info & 0xFFFF;
+        const bool up = info & (1 << 16), down = info & (1 << 17), left = info & (1 << 18), right = info & (1 << 19);
+        const float4 *row = (const float4 *)(img + ctr * 36) + cq;
+        float4 m = row[0];
+#define POOL_MAX(ok, off)                                                                                       \
+        if (ok) { const float4 v = row[(off) * 9]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+        POOL_MAX(left, -1) POOL_MAX(right, 1)
+        POOL_MAX(up, -S_w) POOL_MAX(up && left, -S_w - 1) POOL_MAX(up && right, -S_w + 1)
+        POOL_MAX(down, S_w) POOL_MAX(down && left, S_w - 1) POOL_MAX(down && right, S_w + 1)
+#undef POOL_MAX
+        o4[pq * 8 + cq] = m;
     }
 }
 
@@ -2560,9 +2640,51 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
     return RP_OK;
 }
 
-extern "C" int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev) {
-    if (!ctx || !w_dev || !frag_dev) return fail(ctx, RP_ERR_ARG, "rp_nn_pack_conv32: bad argument");
-    hipLaunchKernelGGL(k_pack_conv32, dim3(36), dim3(256), 0, ctx->stream, w_dev, frag_dev);
+extern "C" int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev, int32_t Cin) {
+    if (!ctx || !w_dev || !frag_dev || (Cin != 16 && Cin != 32)) return fail(ctx, RP_ERR_ARG, "rp_nn_pack_conv32: bad argument (Cin 16 or 32)");
+    const int n = 9 * (Cin / 4) * 64 * 2;
+    hipLaunchKernelGGL(k_pack_conv32, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w_dev, frag_dev, (int)Cin);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *frag_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t Cin, int32_t H,
+                                int32_t W) {
+    if (!ctx || !x_dev || !frag_dev || !bias_dev || !out_dev || B < 0 || H < 1 || W < 1 || (Cin != 16 && Cin != 32) || H * W > (Cin == 16 ? 112 : 80))
+        return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: bad argument (Cin 16: <= 112 pixels, Cin 32: <= 80 pixels)");
+    if (B == 0) return RP_OK;
+    const int PIX = H * W, stride = Cin + 1, max_tiles = Cin == 16 ? 7 : 5;
+    const size_t img_floats = (size_t)(H + 2) * (W + 2) * stride;
+    int imgw = (16 * max_tiles) / PIX;
+    const int PPn = ((H + 1) / 2) * ((W + 1) / 2);
+    auto wave_floats = [&](int k) { return (std::max<size_t>(k * img_floats, (size_t)k * PIX * 36) + 3) & ~(size_t)3; };
+    auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + (((size_t)k * PPn + 3) & ~(size_t)3) + 4 * wave_floats(k)) * sizeof(float); };
+    while (imgw > 1 && lds_bytes(imgw) > 80 * 1024) --imgw;  // two workgroups per CU
+    const int nt = (imgw * PIX + 15) / 16;
+    const size_t wf = wave_floats(imgw), lds = lds_bytes(imgw);
+    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: %dx%d image does not fit LDS", H, W);
+    const long long tasks = (B + imgw - 1) / imgw;
+    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+#define CP_LAUNCH(NT_, KS_)                                                                                                                          \
+    {                                                                                                                                                \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((k_convpool32<NT_, KS_>), grid, block, lds, ctx->stream, x_dev, (const float4 *)frag_dev, bias_dev, out_dev, (long long)B, (int)H,  \
+                           (int)W, imgw, (int)wf);                                                                                                   \
+    }
+    if (Cin == 16) {
+        switch (nt) {
+            case 1: CP_LAUNCH(1, 4) break; case 2: CP_LAUNCH(2, 4) break; case 3: CP_LAUNCH(3, 4) break; case 4: CP_LAUNCH(4, 4) break;
+            case 5: CP_LAUNCH(5, 4) break; case 6: CP_LAUNCH(6, 4) break; case 7: CP_LAUNCH(7, 4) break;
+            default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
+        }
+    } else {
+        switch (nt) {
+            case 1: CP_LAUNCH(1, 8) break; case 2: CP_LAUNCH(2, 8) break; case 3: CP_LAUNCH(3, 8) break; case 4: CP_LAUNCH(4, 8) break;
+            case 5: CP_LAUNCH(5, 8) break;
+            default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
+        }
+    }
+#undef CP_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }

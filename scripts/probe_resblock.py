@@ -42,7 +42,16 @@ for (B, H) in ((10923, 5), (10923, 3)):
     ws = [torch.randn(32, 32, 3, 3, device="cuda") * 0.05 for _ in range(4)]
     f4 = torch.empty(4 * 36 * 64 * 4, device="cuda"); b4 = torch.randn(128, device="cuda")
     for k, w in enumerate(ws):
-        eng.nn_pack_conv32(w, f4[k * 9216:(k + 1) * 9216])
+        eng.nn_pack_conv32(w.contiguous(), f4[k * 9216:(k + 1) * 9216])
     out = torch.empty_like(x)
     t = timeit(lambda: eng.nn_resstage32(x, f4, b4, out, None))
     print(f"B={B} {H}x{H}x32: rp_nn_resstage32 (two blocks) {t:.0f} us ({4*2*B*32*32*9*H*H/t/1e6:.1f} TF)", flush=True)
+
+for (cin, H) in ((16, 10), (32, 5)):
+    B = 10923
+    x = torch.randn(B, cin, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(32, cin, 3, 3, device="cuda") * 0.05).contiguous(); b = torch.randn(32, device="cuda")
+    f = torch.empty(9 * cin * 32, device="cuda"); eng.nn_pack_conv32(w, f)
+    out = torch.empty(B, 32, (H + 1) // 2, (H + 1) // 2, device="cuda").contiguous(memory_format=torch.channels_last)
+    t = timeit(lambda: eng.nn_convpool32(x, f, b, out))
+    print(f"B={B} {H}x{H}x{cin}->32 + pool: rp_nn_convpool32 {t:.0f} us ({2*B*cin*32*9*H*H/t/1e6:.1f} TF)", flush=True)

@@ -391,3 +391,29 @@ def test_fused_resstage32_kernel_matches_pytorch_blocks():
     assert dpi <= 1e-6 and dv <= 1e-5
     net.nnet._dense.clear()
     eng.close()
+
+
+def test_fused_convpool32_kernel_matches_pytorch_conv_and_pool():
+    """rp_nn_convpool32 (first convolution of a 32-channel stage + bias + 3x3/2 max-pool on the FP32 matrix cores) against
+    conv2d + max_pool2d through PyTorch, for both input widths and odd / even image sizes."""
+    import torch
+    import torch.nn.functional as F
+    from resource_packing_self_play_amd import _lib
+    eng = _lib.Engine(20, 20, 32, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(6)
+    cases = [(16, 5, 10, 10), (16, 1030, 10, 10), (16, 33, 7, 9), (16, 9, 3, 3), (16, 4, 1, 1), (16, 21, 8, 13), (16, 64, 4, 4),
+             (32, 5, 5, 5), (32, 1030, 5, 5), (32, 3001, 3, 3), (32, 17, 8, 8), (32, 11, 7, 9), (32, 6, 2, 5), (32, 3, 1, 1), (32, 10, 8, 10)]
+    for (cin, B, H, W) in cases:
+        conv = torch.nn.Conv2d(cin, 32, 3, padding=1).cuda()
+        frag = torch.empty(9 * cin * 32, device="cuda")
+        eng.nn_pack_conv32(conv.weight.detach().contiguous(), frag)
+        x = torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            want = F.max_pool2d(conv(x), kernel_size=3, stride=2, padding=1)
+        out = torch.empty_like(want).contiguous(memory_format=torch.channels_last)
+        eng.nn_convpool32(x, frag, conv.bias.detach(), out)
+        torch.cuda.synchronize()
+        err = float((out - want).abs().max())
+        print("convpool32 Cin=%d B=%d %dx%d: max |delta| %.3e" % (cin, B, H, W, err))
+        assert err <= 2e-5
+    eng.close()
