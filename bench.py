@@ -149,7 +149,8 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=24, help="legal-move arena = node arena x this (6 B per entry)")
     ap.add_argument("--vis-factor", type=float, default=1.5, help="visited-edge arena = node arena x this (26 B per entry)")
     ap.add_argument("--no-reclaim", action="store_true", help="keep dead levels' arena chunks (needs ~5x the arena)")
-    ap.add_argument("--groups", type=int, default=3, help="slot groups per GPU, each with its own stream (tree walk of one overlaps the CNN of another)")
+    ap.add_argument("--groups", type=int, default=1, help="slot groups per GPU, each with its own stream and graph; 3 co-schedules the groups' kernels "
+                    "(+4 %% episodes/s) but then no kernel has the GPU to itself and per-kernel durations stop meaning anything")
     ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-fuse", action="store_true", help="leave bias / ReLU / skip / pool to PyTorch's own element-wise kernels")
@@ -204,11 +205,13 @@ def main():
     ev_every = max(1, a.event_every)
     phase_ms = np.zeros(4)  # search, planes, evaluator, commit
     phase_n = 0
+    kev, kernel_ms = [], {}
 
     def play_pool(step_idx, timed):
         nonlocal phase_ms, phase_n
-        wh = make_instances(W, H, N, pool, 100 + (step_idx * world + rank) * pool)
-        sp.start(wh, np.full(pool, W * H, np.int32), buf, first_id=0)
+        # instances = ItemsGenerator.items_generator(seed), seeds 100 + index as in main_bpp.py:33, generated on the device
+        # (bit-identical to the host generator; 32 768 instances through the Python generator would cost seconds of host time)
+        sp.start_from_seeds(np.arange(pool, dtype=np.uint32) + np.uint32(100 + (step_idx * world + rank) * pool), buf, first_id=0)
         waves = 0
         pending = []
         g0 = sp.groups[0]
@@ -219,8 +222,9 @@ def main():
                         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                         ev[0].record(); g0.eng.search_step(sync=False)
                         ev[1].record(); g0.eng.leaf_stem(g0.stem.data_ptr(), g0.G, g0.stem_relu.data_ptr() if g0.stem_relu is not None else None, g0.channels_last) if g0.use_stem else g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
+                        g0.eng.kernel_events = kev
                         ev[2].record(); pi, v = g0.forward(sp.nnet)
-                        ev[3].record(); g0.eng.commit_eval(pi.data_ptr(), v.data_ptr())
+                        ev[3].record(); g0.eng.kernel_events = None; g0.eng.commit_eval(pi.data_ptr(), v.data_ptr())
                         ev[4].record()
                     for g in sp.groups[1:]:
                         sp.step_group(g)
@@ -239,6 +243,9 @@ def main():
         for ev, _, _ in pending:
             phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
             phase_n += 1
+        for name, e0, e1 in kev:
+            kernel_ms.setdefault(name, []).append(e0.elapsed_time(e1))
+        del kev[:]
         ids, _, score, moves = sp.pop_finished()
         assert len(ids) == pool, "pool not finished: %d of %d" % (len(ids), pool)
         return waves, float(np.mean(score)), float(np.mean(moves))
@@ -289,7 +296,54 @@ def main():
     launches = max(tot["waves"], 1) * len(sp.groups)  # one k_search / evaluator / k_commit launch per group and wave
     tree_bytes_per_wave = tree_bytes / launches
     leaves_per_wave = tot["expansions"] / launches
-    nn_tflops = sp.groups[0].G * flops_leaf / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
+    stem_flops = 2 * 9 * (N + 1) * 16 * H * W if sp.use_stem else 0  # first convolution: replaced by table sums in k_leaf_stem, not matrix-core work
+    nn_tflops = sp.groups[0].G * (flops_leaf - stem_flops) / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
+    # roofline of the dominant kernel: the fused MFMA kernel with the largest measured time (HIP events around its launches in the
+    # event-timed waves, other groups' kernels running beside it).  Algorithmic flops = 2 * 9 * Cin * Cout * pixels per convolution.
+    Gs = sp.groups[0].G
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    kflops = {"k_resstage16 %dx%d" % (Hs, Ws): 4 * 2 * 9 * 16 * 16 * Hs * Ws,
+              "k_convpool32 16->32 %dx%d" % (Hs, Ws): 2 * 9 * 16 * 32 * Hs * Ws}
+    Hs2, Ws2 = (Hs + 1) // 2, (Ws + 1) // 2
+    kflops["k_resstage32 %dx%d" % (Hs2, Ws2)] = 4 * 2 * 9 * 32 * 32 * Hs2 * Ws2
+    kflops["k_convpool32 32->32 %dx%d" % (Hs2, Ws2)] = 2 * 9 * 32 * 32 * Hs2 * Ws2
+    Hs3, Ws3 = (Hs2 + 1) // 2, (Ws2 + 1) // 2
+    kflops["k_resstage32 %dx%d" % (Hs3, Ws3)] = 4 * 2 * 9 * 32 * 32 * Hs3 * Ws3
+    kbytes = {"k_resstage16 %dx%d" % (Hs, Ws): 2 * 4 * 16 * Hs * Ws}  # x in, result out, per leaf
+    roof = None
+    if kernel_ms:
+        kname = max((k for k in kernel_ms if k in kflops), key=lambda k: np.mean(kernel_ms[k]), default=None)
+        if kname is not None:
+            kms = float(np.mean(kernel_ms[kname]))
+            ach = Gs * kflops[kname] / (kms * 1e-3) / 1e12
+            traffic = None
+            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+            if os.path.exists(tfile):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled, MI355X_MICROARCH.md)
+                rec = json.load(open(tfile)).get(kname.split(" ")[0])
+                if rec and rec.get("leaves_per_launch") == Gs:
+                    traffic = rec["hbm_bytes_per_launch"]
+            roof = {"kernel": kname + " (FP32 MFMA, own HIP kernel)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "flops_per_launch": Gs * kflops[kname], "ms_per_launch": kms,
+                    "launches_timed": len(kernel_ms[kname]), "algorithmic_bytes_per_launch": Gs * kbytes.get(kname, 0) or None}
+    if roof is not None and roof["kernel"].startswith("k_resstage16") and "stagefrag:0" in getattr(sp.nnet.nnet, "_dense", {}):
+        # the same kernel on the same tensors with the GPU to itself (after the timed region): what the co-scheduled figure above
+        # costs in isolation; profiles/ holds the rocprofv3 summaries of both situations
+        g0 = sp.groups[0]
+        dn = sp.nnet.nnet._dense
+        with torch.cuda.stream(g0.stream):
+            o = torch.empty_like(g0.stem)
+            g0.eng.kernel_events = solo = []
+            for _ in range(24):
+                g0.eng.nn_resstage16(g0.stem, dn["stagefrag:0"], dn["stagebias:0"], o, None)
+            g0.eng.kernel_events = None
+        torch.cuda.synchronize(dev)
+        solo_ms = float(np.mean([e0.elapsed_time(e1) for _, e0, e1 in solo[4:]]))
+        roof["standalone"] = {"ms_per_launch": solo_ms, "achieved": roof["flops_per_launch"] / (solo_ms * 1e-3) / 1e12,
+                              "frac": roof["flops_per_launch"] / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        roof["note"] = "achieved/frac: HIP events around the kernel's launches inside the timed region (with --groups > 1 other groups' kernels share the GPU); standalone: the same launch after the timed region"
+    if roof is None:
+        roof = {"kernel": "CNN evaluator (all kernels of one forward over the slot batch)", "bound": "mfma", "achieved": nn_tflops,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
     out = {
         "metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": episodes / dt, "unit": "episodes/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -305,9 +359,12 @@ def main():
                        "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
                        "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
         "phase_ms_per_launch": {"search": per_wave[0], "leaf_stem" if sp.use_stem else "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
-        "roofline": {"kernel": "CNN evaluator (all PyTorch-ROCm kernels of one forward over the slot batch)", "bound": "mfma",
-                     "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
-                     "traffic": None, "flops_per_leaf": flops_leaf, "leaves_per_launch": sp.groups[0].G},
+        "roofline": roof,
+        "roofline_evaluator": {"kernel": "whole CNN evaluator after the stem (fused MFMA kernels + hipBLASLt heads) over the slot batch", "bound": "mfma",
+                               "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": None, "flops_per_leaf": flops_leaf - stem_flops, "flops_per_leaf_with_first_conv": flops_leaf,
+                               "leaves_per_launch": sp.groups[0].G},
+        "kernel_ms_per_launch": {k: float(np.mean(v)) for k, v in sorted(kernel_ms.items())},
         "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm",
                           "achieved": tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": (tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0, "traffic": None,

@@ -283,6 +283,19 @@ class Engine:
             raise ValueError("tensor must be contiguous")
         return x.shape[0], x.shape[1], x[0, 0].numel()
 
+    kernel_events = None  # measurement aid: a list -> (name, start event, end event) of every fused evaluator kernel launched
+
+    def _timed(self, name, call):
+        sink = self.kernel_events
+        if sink is None:
+            return call()
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # torch's current stream: the one this engine was created on, in BatchedSelfPlay's groups
+        call()
+        e1.record()
+        sink.append((name, e0, e1))
+
     def nn_pack_conv16(self, weight, frag):
         """weight: contiguous float32 [16, 16, 3, 3]; frag: float32 [36 * 64] buffer to fill (MFMA B-fragment order)."""
         self._ck(self.L.rp_nn_pack_conv16(self.h, C.c_void_p(weight.data_ptr()), C.c_void_p(frag.data_ptr())))
@@ -301,8 +314,9 @@ class Engine:
         B, Cc, H, W = x.shape
         if Cc != 16 or self._bchw(x)[2] != 1 or H * W > 128:
             raise ValueError("nn_resstage16 needs a channels-last [B, 16, H, W] tensor with H * W <= 128")
-        self._ck(self.L.rp_nn_resstage16(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()),
-                                         C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
+        self._timed("k_resstage16 %dx%d" % (H, W), lambda: self._ck(self.L.rp_nn_resstage16(
+            self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()), C.c_void_p(out.data_ptr()),
+            C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W)))
 
     def nn_pack_conv32(self, weight, frag):
         """weight: contiguous float32 [32, Cin, 3, 3], Cin 16 or 32; frag: float32 [9 * Cin * 32] buffer to fill (streaming
@@ -314,16 +328,17 @@ class Engine:
         B, Cc, H, W = x.shape
         if self._bchw(x)[2] != 1 or self._bchw(out)[2] != 1:
             raise ValueError("nn_convpool32 needs channels-last tensors")
-        self._ck(self.L.rp_nn_convpool32(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag.data_ptr()), C.c_void_p(bias.data_ptr()),
-                                         C.c_void_p(out.data_ptr()), B, Cc, H, W))
+        self._timed("k_convpool32 %d->32 %dx%d" % (Cc, H, W), lambda: self._ck(self.L.rp_nn_convpool32(
+            self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, Cc, H, W)))
 
     def nn_resstage32(self, x, frag4, bias4, out, out_relu=None):
         """Both residual blocks of a 32-channel stage on channels-last x [B, 32, H, W] (H * W <= 80) in one launch."""
         B, Cc, H, W = x.shape
         if Cc != 32 or self._bchw(x)[2] != 1 or H * W > 80:
             raise ValueError("nn_resstage32 needs a channels-last [B, 32, H, W] tensor with H * W <= 80")
-        self._ck(self.L.rp_nn_resstage32(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()),
-                                         C.c_void_p(out.data_ptr()), C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
+        self._timed("k_resstage32 %dx%d" % (H, W), lambda: self._ck(self.L.rp_nn_resstage32(
+            self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()), C.c_void_p(out.data_ptr()),
+            C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W)))
 
     def nn_bias_relu(self, x, bias):
         B, Cc, inner = self._bchw(x)

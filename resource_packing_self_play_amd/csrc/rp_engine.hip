@@ -65,6 +65,14 @@ struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
 #define HF_FALLBACK 2u
 __host__ __device__ inline u32 hdr_term_kind(const NodeHdr &h) { return (h.flags >> 2) & 3u; }
 
+// Instance pool of auto_restart, in DEVICE memory: kernel arguments are baked into captured HIP graphs, the pool changes between
+// pools of one BatchedSelfPlay (size, episode-id base, even the buffers when it grows), so restarting slots read it from here.
+struct PoolDesc {
+    long long n_instances;
+    unsigned long long first_id;
+    const unsigned char *wh;  // [n_instances][N][2]
+    const int *area, *max_h;
+};
 struct DP {  // device view of a context, passed by value to every kernel
     int W, H, N, A, G, sims, node_cap, edge_cap, vis_cap, table_cap, KW, RW, RMW, move_rule;
     int reclaim;   // 1: a level's legal-move runs and visited blocks are recycled once the root has moved past it
@@ -126,6 +134,7 @@ struct DP {  // device view of a context, passed by value to every kernel
     u64 first_id;
     const u8 *pool_wh;      // [n_instances][N][2]
     const int *pool_area, *pool_max_h;
+    const PoolDesc *pool_desc;  // device copy of the five fields above (what the kernels read)
     unsigned long long *next_instance;
     // replay buffer (CoachBPP.executeEpisode's trainExamples, CoachBPP.py:80,99)
     long long max_examples;
@@ -799,17 +808,18 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
     unsigned long long idx = 0;
     if (lane == 0) idx = atomicAdd(p.next_instance, 1ull);
     idx = __shfl(idx, 0);
-    if ((long long)idx >= p.n_instances) {
+    const PoolDesc pd = *p.pool_desc;
+    if ((long long)idx >= pd.n_instances) {
         if (lane == 0) p.phase[g] = RP_PHASE_IDLE;
         return;
     }
     u8 *wh = p.item_wh + (size_t)g * p.N * 2;
-    const u8 *src = p.pool_wh + (size_t)idx * p.N * 2;
+    const u8 *src = pd.wh + (size_t)idx * p.N * 2;
     for (int q = lane; q < 2 * p.N; q += 64) wh[q] = src[q];
     for (int s = lane; s < p.table_cap; s += 64) t.table[s] = 0ull;
     if (lane == 0) {
-        p.total_area[g] = p.pool_area[idx]; p.max_h[g] = p.pool_max_h[idx];
-        p.episode[g] = p.first_id + idx; p.moves[g] = 0; p.sims_done[g] = 0;
+        p.total_area[g] = pd.area[idx]; p.max_h[g] = pd.max_h[idx];
+        p.episode[g] = pd.first_id + idx; p.moves[g] = 0; p.sims_done[g] = 0;
         p.bl[g] = *p.g_bl; p.has_buf[g] = *p.g_has_buf;
         p.last_outcome[g] = 0; p.last_score[g] = 0.0;
     }
@@ -2278,6 +2288,12 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.fin_count, 1); A_(d.fin_episode, d.fin_cap); A_(d.fin_outcome, d.fin_cap); A_(d.fin_moves, d.fin_cap); A_(d.fin_score, d.fin_cap);
     d.auto_restart = cfg->auto_restart; d.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
     A_(d.next_instance, 1); A_(d.ex_count, 1); A_(d.slot_ex, G * N);
+    {
+        PoolDesc *pd_dev = nullptr;
+        A_(pd_dev, 1);
+        if (rc == RP_OK && hipMemset(pd_dev, 0, sizeof(PoolDesc)) != hipSuccess) rc = RP_ERR_DEVICE;
+        d.pool_desc = pd_dev;
+    }
     if (d.max_examples > 0) {
         A_(d.ex_key, (size_t)d.max_examples * d.KW); A_(d.ex_wh, (size_t)d.max_examples * N * 2);
         A_(d.ex_counts, (size_t)d.max_examples * d.A); A_(d.ex_value, (size_t)d.max_examples);
@@ -2852,6 +2868,8 @@ extern "C" int rp_set_instance_pool(rp_ctx *ctx, int64_t n_instances, const uint
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     d.pool_wh = ctx->pool_wh; d.pool_area = ctx->pool_area; d.pool_max_h = ctx->pool_max_h;
     d.n_instances = n_instances; d.first_id = first_id;
+    const PoolDesc pd = {(long long)n_instances, (unsigned long long)first_id, ctx->pool_wh, ctx->pool_area, ctx->pool_max_h};
+    HIPCHK(ctx, hipMemcpy((void *)d.pool_desc, &pd, sizeof pd, hipMemcpyHostToDevice));
     return RP_OK;
 }
 
@@ -2907,6 +2925,8 @@ extern "C" int rp_set_instance_pool_seeds(rp_ctx *ctx, int64_t n_instances, cons
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     d.pool_wh = ctx->pool_wh; d.pool_area = ctx->pool_area; d.pool_max_h = ctx->pool_max_h;
     d.n_instances = n_instances; d.first_id = first_id;
+    const PoolDesc pd = {(long long)n_instances, (unsigned long long)first_id, ctx->pool_wh, ctx->pool_area, ctx->pool_max_h};
+    HIPCHK(ctx, hipMemcpy((void *)d.pool_desc, &pd, sizeof pd, hipMemcpyHostToDevice));
     return RP_OK;
 }
 

@@ -183,6 +183,25 @@ class BatchedSelfPlay:
             g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), 0))
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
+    def start_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None):
+        """Like start(), with instance i = ItemsGenerator.items_generator(seeds[i]) of the W x bin_h rectangle generated on the
+        device (rp_set_instance_pool_seeds: bit-identical to the host generator, tests/test_gpu_rules.py); total area W * bin_h."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(-1)
+        buf = np.asarray(list(rewards_list), dtype=np.float64)
+        self.first_id = int(first_id)
+        self.n_instances = seeds.shape[0]
+        k = len(self.groups)
+        torch.cuda.synchronize(self.device)
+        if self.fuse_elementwise and self.dense_small_convs:
+            self.nnet.refresh_fused()
+            torch.cuda.synchronize(self.device)
+        for g in self.groups:
+            with torch.cuda.stream(g.stream):
+                g.refresh_weights(self.nnet)
+            g.eng.set_rank_buffer(buf)
+            g.eng.set_instance_pool_seeds(np.ascontiguousarray(seeds[g.index::k]), self.W, bin_h or self.H, 0)
+            g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
+
     def active(self):
         n = 0
         for g in self.groups:
@@ -215,6 +234,14 @@ class BatchedSelfPlay:
         """Plays every instance of the pool to the end.  Returns (episode ids, outcomes, scores, moves) sorted by id,
         plus timing / counter statistics."""
         self.start(item_wh, total_area, rewards_list, first_id)
+        return self._play_out(poll, max_steps)
+
+    def run_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None, poll=16, max_steps=None):
+        """run() on device-generated instances (start_from_seeds)."""
+        self.start_from_seeds(seeds, rewards_list, first_id, bin_h)
+        return self._play_out(poll, max_steps)
+
+    def _play_out(self, poll, max_steps):
         t0 = time.time()
         steps0 = self.steps
         while self.active() > 0:

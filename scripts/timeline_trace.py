@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-MFMA = ("k_resblock", "Cijk_", "igemm_", "grouped_conv", "k_trunk")
+MFMA = ("k_resblock", "k_resstage", "k_convpool", "Cijk_", "igemm_", "grouped_conv")
 
 
 def main(src, out, tail=0.5):

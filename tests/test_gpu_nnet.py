@@ -417,3 +417,33 @@ def test_fused_convpool32_kernel_matches_pytorch_conv_and_pool():
         print("convpool32 Cin=%d B=%d %dx%d: max |delta| %.3e" % (cin, B, H, W, err))
         assert err <= 2e-5
     eng.close()
+
+
+def test_batched_selfplay_from_seeds_equals_host_generated_pool():
+    """BatchedSelfPlay.run_from_seeds (instances generated on the device from generator seeds) plays the same episodes as run()
+    on the instances the host ItemsGenerator makes for those seeds."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    from resource_packing_self_play_amd.selfplay import BatchedSelfPlay
+    d = np.load(os.path.join(GOLDEN, "nnet_c2_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    args.numMCTSSims, args.cpuct, args.alpha = 12, 1, 0.75
+    W, H, N = game.bin_width, game.bin_height, game.num_items
+    seeds = np.arange(20, dtype=np.uint32) + 4000
+    gen = ItemsGenerator(W, H, N)
+    state = np.random.get_state()
+    wh = np.array([[it[:2] for it in gen.items_generator(int(sd))] for sd in seeds], dtype=np.uint8)
+    np.random.set_state(state)
+    res = []
+    for mode in ("host", "seeds"):
+        sp = BatchedSelfPlay(game, net, args, games=8, move_rule=_lib.MOVE_SAMPLE, seed=11, groups=2)
+        sp.prepare()
+        if mode == "host":
+            out = sp.run(wh, np.full(len(seeds), W * H, np.int32), rewards_list=[0.9, 0.95, 1.0])
+        else:
+            out = sp.run_from_seeds(seeds, rewards_list=[0.9, 0.95, 1.0])
+        res.append(out[:4])
+        assert len(out[0]) == len(seeds)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
