@@ -174,7 +174,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_base = None
-    if rank == 0 and not a.no_cpu_baseline:  # before this process touches the GPU
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.sims:  # N = 1 only, the configured workload only; before this process touches the GPU
         cpu_base = run_cpu_baseline(a.config, a.cpu_budget)
 
     import torch

@@ -840,8 +840,11 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
 // ------------------------------------------------------------------------------------------------
 // MCTS.search (MCTS_bpp.py:56-139) for all slots: each wave runs simulations of its game until one
 // needs the evaluator or the move's budget is spent.
+#ifndef SEARCH_WAVES
+#define SEARCH_WAVES 3
+#endif
 template <typename row_t>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 3) k_search(DP p) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(DP p) {
     __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     u32 *vmask = s_vmask[threadIdx.x >> 6];
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
@@ -1815,12 +1818,19 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
 // an L2-hot re-read in accumulator layout) and one write of the result -- the intermediate block output, its ReLU copy and the
 // second kernel's launch tail are gone.  B fragments (36 VGPRs) are re-read from L2 per convolution to leave room for 3 waves
 // per SIMD.  frag = [4][36][64], bias = [4][16] in execution order (b0c0, b0c1, b1c0, b1c1).
+#ifndef RS_LB
+#define RS_LB 2
+#endif
+#ifndef RS_SCHED
+#define RS_SCHED 0
+#endif
 template <int NT>
 __device__ __forceinline__ void rs_conv(const float *img, const float *__restrict__ frag, int PW, const int (&abase)[NT], f32x4 (&acc)[NT]) {
     const int lane = lane_id();
-    float bf[36];
+    constexpr int PF = 8;  // B fragments in flight: k-step s + PF is loaded from L2 while step s feeds the matrix cores
+    float bq[PF];
 #pragma unroll
-    for (int s = 0; s < 36; ++s) bf[s] = frag[s * 64 + lane];
+    for (int s = 0; s < PF; ++s) bq[s] = frag[s * 64 + lane];
     float a_cur[NT], a_nxt[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
@@ -1832,14 +1842,19 @@ __device__ __forceinline__ void rs_conv(const float *img, const float *__restric
 #pragma unroll
             for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
         }
+        const float b = bq[s % PF];
+        if (s + PF < 36) bq[s % PF] = frag[(s + PF) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], bf[s], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+#if RS_SCHED
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at one k-step
+#endif
     }
 }
 template <int NT>
-__global__ void __launch_bounds__(256, 2) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
+__global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
