@@ -1855,20 +1855,24 @@ __device__ __forceinline__ void rs_conv(const float *img, const float *__restric
 }
 template <int NT>
 __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
-                                                       float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w) {
+                                                           float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE;
-    int *ptab = (int *)rb_lds;  // [PIX] padded LDS offset of every pixel's channel 0 (shared by the block)
-    float *img = rb_lds + ((PIX + 3) & ~3) + (size_t)wv * IMG;
-    for (int i = threadIdx.x; i < PIX; i += blockDim.x) { int r = i / S_w, c = i - r * S_w; ptab[i] = ((r + 1) * PW + c + 1) * RB_STRIDE; }
-    for (int i = lane; i < IMG; i += 64) img[i] = 0.f;  // the border stays zero
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE, MP = IMGW * PIX;
+    int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
+    float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
+    for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+        int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
+        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * RB_STRIDE : 0;
+    }
+    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;  // borders (and missing leaves of the last group) stay zero
     __syncthreads();
-    const long long leaf = (long long)blockIdx.x * 4 + wv;
-    if (leaf >= B) return;
-    const float *xl = x + (size_t)leaf * PIX * 16;
-    float *ol = out + (size_t)leaf * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr;
-    for (int e4 = lane; e4 < PIX * 4; e4 += 64) {  // relu(x) into the padded image, 16 bytes per lane
+    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    if (leaf0 >= B) return;
+    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
+    const float *xl = x + (size_t)leaf0 * PIX * 16;
+    float *ol = out + (size_t)leaf0 * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 16 : nullptr;
+    for (int e4 = lane; e4 < npix * 4; e4 += 64) {  // relu(x) into the padded images, 16 bytes per lane
         float4 v = ((const float4 *)xl)[e4];
         float *d = img + ptab[e4 >> 2] + 4 * (e4 & 3);
         d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
@@ -1877,7 +1881,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int m = t * 16 + (lane & 15);
-        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
     }
     const int c = lane & 15;
     const float b0 = bias[c], b1 = bias[16 + c], b2 = bias[32 + c], b3 = bias[48 + c];
@@ -1887,7 +1891,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < PIX) img[ptab[m] + c] = fmaxf(acc[t][q] + b0, 0.f); }
+        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < npix) img[ptab[m] + c] = fmaxf(acc[t][q] + b0, 0.f); }
     wave_sync();
     rs_conv<NT>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
 #pragma unroll
@@ -1896,7 +1900,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
         for (int q = 0; q < 4; ++q) {
             int m = t * 16 + (lane >> 4) * 4 + q;
             float y = 0.f;
-            if (m < PIX) { y = (acc[t][q] + b1) + xl[m * 16 + c]; img[ptab[m] + c] = fmaxf(y, 0.f); }
+            if (m < npix) { y = (acc[t][q] + b1) + xl[m * 16 + c]; img[ptab[m] + c] = fmaxf(y, 0.f); }
             y1[t][q] = y;
         }
     wave_sync();
@@ -1904,7 +1908,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < PIX) img[ptab[m] + c] = fmaxf(acc[t][q] + b2, 0.f); }
+        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < npix) img[ptab[m] + c] = fmaxf(acc[t][q] + b2, 0.f); }
     wave_sync();
     rs_conv<NT>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
 #pragma unroll
@@ -1912,7 +1916,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int m = t * 16 + (lane >> 4) * 4 + q;
-            if (m < PIX) {
+            if (m < npix) {
                 float y = (acc[t][q] + b3) + y1[t][q];
                 ol[m * 16 + c] = y;
                 if (orl) orl[m * 16 + c] = fmaxf(y, 0.f);
@@ -2654,13 +2658,20 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
     if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 128)
         return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: bad argument (images of at most 128 pixels)");
     if (B == 0) return RP_OK;
-    const size_t lds = ((size_t)4 * (H + 2) * (W + 2) * RB_STRIDE + (((size_t)H * W + 3) & ~(size_t)3)) * sizeof(float);
-    const int nt = (H * W + 15) / 16;
-    const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+    const int PIX = H * W;
+    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * RB_STRIDE * sizeof(float);
+    // leaves per wave: as many as fit 8 pixel tiles (accumulators + the kept skip operand in registers; 13 tiles = two 10x10 leaves
+    // need all 256 VGPRs and measured 246 us against 233 us per 10 923 leaves) and two workgroups per CU
+    int imgw = std::max(1, (16 * 8) / PIX);
+    while (imgw > 1 && 4 * imgw * img_bytes + 1024 > 78 * 1024) --imgw;
+    const int nt = (imgw * PIX + 15) / 16;
+    const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * imgw * img_bytes;
+    const long long tasks = (B + imgw - 1) / imgw;
+    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W); \
+        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw); \
         break;
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
