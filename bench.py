@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-dense", action="store_true", help="keep <= 3x3-image convolutions on MIOpen instead of one GEMM each")
     ap.add_argument("--no-resblock", action="store_true", help="16-channel residual blocks through MIOpen + fused element-wise kernels instead of rp_nn_resblock16")
     ap.add_argument("--nchw", action="store_true", help="keep the evaluator's activations NCHW instead of channels-last")
+    ap.add_argument("--no-compact", action="store_true", help="evaluator row b = slot b (every slot costs convolution work) instead of the waiting slots only")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -199,7 +200,7 @@ def main():
         edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * 4096), max(vis_cap, (min(sims, N) + 3) * 1024)
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=edge_cap, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
-                         reclaim=not a.no_reclaim, vis_cap=vis_cap, channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
+                         reclaim=not a.no_reclaim, vis_cap=vis_cap, compact_rows=not a.no_compact, channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
     buf = rank_buffer()
     ev_every = max(1, a.event_every)
@@ -297,7 +298,13 @@ def main():
     tree_bytes_per_wave = tree_bytes / launches
     leaves_per_wave = tot["expansions"] / launches
     stem_flops = 2 * 9 * (N + 1) * 16 * H * W if sp.use_stem else 0  # first convolution: replaced by table sums in k_leaf_stem, not matrix-core work
-    nn_tflops = sp.groups[0].G * (flops_leaf - stem_flops) / (per_wave[2] * 1e-3) / 1e12 if per_wave[2] > 0 else 0.0
+    # evaluator time per wave: with one slot group the waves run back to back, so it is the wall time per wave minus the three engine
+    # phases (single kernels, timed by events); the eagerly launched evaluator of the event-timed waves also carries the host's
+    # launch gaps between its ~12 kernels and is only the fallback for --groups > 1
+    eval_ms = per_wave[2]
+    if len(sp.groups) == 1 and tot["waves"] > 0:
+        eval_ms = dt * 1e3 / tot["waves"] - (per_wave[0] + per_wave[1] + per_wave[3])
+    nn_tflops = (leaves_per_wave if sp.compact_rows else sp.groups[0].G) * (flops_leaf - stem_flops) / (eval_ms * 1e-3) / 1e12 if eval_ms > 0 else 0.0
     # roofline of the dominant kernel: the fused MFMA kernel with the largest measured time (HIP events around its launches in the
     # event-timed waves, other groups' kernels running beside it).  Algorithmic flops = 2 * 9 * Cin * Cout * pixels per convolution.
     Gs = sp.groups[0].G
@@ -315,21 +322,24 @@ def main():
         kname = max((k for k in kernel_ms if k in kflops), key=lambda k: np.mean(kernel_ms[k]), default=None)
         if kname is not None:
             kms = float(np.mean(kernel_ms[kname]))
-            ach = Gs * kflops[kname] / (kms * 1e-3) / 1e12
+            # with compact rows the kernel processes the waiting leaves only: mean leaves per launch from the engine's counters
+            Ls = leaves_per_wave if sp.compact_rows else Gs
+            ach = Ls * kflops[kname] / (kms * 1e-3) / 1e12
             traffic = None
             tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled, MI355X_MICROARCH.md)
                 rec = json.load(open(tfile)).get(kname.split(" ")[0])
-                if rec and rec.get("leaves_per_launch") == Gs:
-                    traffic = rec["hbm_bytes_per_launch"]
+                if rec and rec.get("leaves_per_launch"):  # the PMC passes cover the pool's first waves (every slot waiting): scale per leaf
+                    traffic = rec["hbm_bytes_per_launch"] / rec["leaves_per_launch"] * Ls
             roof = {"kernel": kname + " (FP32 MFMA, own HIP kernel)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "flops_per_launch": Gs * kflops[kname], "ms_per_launch": kms,
-                    "launches_timed": len(kernel_ms[kname]), "algorithmic_bytes_per_launch": Gs * kbytes.get(kname, 0) or None}
+                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "flops_per_launch": Ls * kflops[kname], "ms_per_launch": kms,
+                    "leaves_per_launch": Ls, "launches_timed": len(kernel_ms[kname]), "algorithmic_bytes_per_launch": Ls * kbytes.get(kname, 0) or None}
     if roof is not None and roof["kernel"].startswith("k_resstage16") and "stagefrag:0" in getattr(sp.nnet.nnet, "_dense", {}):
         # the same kernel on the same tensors with the GPU to itself (after the timed region): what the co-scheduled figure above
         # costs in isolation; profiles/ holds the rocprofv3 summaries of both situations
         g0 = sp.groups[0]
         dn = sp.nnet.nnet._dense
+        g0.eng.set_compact_rows(False)  # all Gs rows of the (stale) stem buffer: the row limit would read 0 after the last episode
         with torch.cuda.stream(g0.stream):
             o = torch.empty_like(g0.stem)
             g0.eng.kernel_events = solo = []
@@ -338,8 +348,10 @@ def main():
             g0.eng.kernel_events = None
         torch.cuda.synchronize(dev)
         solo_ms = float(np.mean([e0.elapsed_time(e1) for _, e0, e1 in solo[4:]]))
-        roof["standalone"] = {"ms_per_launch": solo_ms, "achieved": roof["flops_per_launch"] / (solo_ms * 1e-3) / 1e12,
-                              "frac": roof["flops_per_launch"] / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        g0.eng.set_compact_rows(sp.compact_rows)
+        solo_fl = Gs * kflops[kname]
+        roof["standalone"] = {"ms_per_launch": solo_ms, "leaves_per_launch": Gs, "achieved": solo_fl / (solo_ms * 1e-3) / 1e12,
+                              "frac": solo_fl / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         roof["note"] = "achieved/frac: HIP events around the kernel's launches inside the timed region (with --groups > 1 other groups' kernels share the GPU); standalone: the same launch after the timed region"
     if roof is None:
         roof = {"kernel": "CNN evaluator (all kernels of one forward over the slot batch)", "bound": "mfma", "achieved": nn_tflops,
@@ -363,7 +375,7 @@ def main():
         "roofline_evaluator": {"kernel": "whole CNN evaluator after the stem (fused MFMA kernels + hipBLASLt heads) over the slot batch", "bound": "mfma",
                                "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
                                "traffic": None, "flops_per_leaf": flops_leaf - stem_flops, "flops_per_leaf_with_first_conv": flops_leaf,
-                               "leaves_per_launch": sp.groups[0].G},
+                               "leaves_per_launch": leaves_per_wave if sp.compact_rows else sp.groups[0].G, "ms_per_launch": eval_ms},
         "kernel_ms_per_launch": {k: float(np.mean(v)) for k, v in sorted(kernel_ms.items())},
         "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm",
                           "achieved": tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -145,6 +145,12 @@ int rp_set_stream(rp_ctx *ctx, void *stream);
  * game hit cached terminal states (Es, MCTS_bpp.py:81-83) and need no evaluator; the cap keeps such a slot from stretching
  * the launch for everyone.  Scheduling only -- results are identical for any value. */
 int rp_set_step_cap(rp_ctx *ctx, int32_t max_sims_per_step);
+/* Compact evaluator rows without a host round trip: with enable != 0, rp_search_step(ctx, NULL) also lists the waiting slots in
+ * slot order on the device (row b = b-th waiting slot, as with a count request), rp_leaf_stem / rp_leaf_planes / rp_commit_eval
+ * follow that list, and the rp_nn_resstage16 / rp_nn_resstage32 / rp_nn_convpool32 launches of this context stop at the number of
+ * waiting leaves (read on the device), so slots that wait for nothing -- finished episodes, terminal streaks -- cost no
+ * convolution work.  Rows past the count hold stale data.  Scheduling only: results do not depend on it. */
+int rp_set_compact_rows(rp_ctx *ctx, int32_t enable);
 /* Switches the move rule; onehot_examples != 0 records pi as a one-hot on the played action, the greedy branch of
  * MCTS.getActionProb (greedy_a == 0, MCTS_bpp.py:43-49) that CoachBPP uses after iterStepThreshold (CoachBPP.py:132). */
 int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples);

@@ -56,6 +56,7 @@ _SIGS = {
     "rp_set_roots": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "rp_set_stream": (C.c_int, [_vp, _vp]),
     "rp_set_step_cap": (C.c_int, [_vp, _i32]),
+    "rp_set_compact_rows": (C.c_int, [_vp, _i32]),
     "rp_set_move_rule": (C.c_int, [_vp, _i32, _i32]),
     "rp_set_sims": (C.c_int, [_vp, _i32]),
     "rp_last_values": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
@@ -230,6 +231,9 @@ class Engine:
         rows = _arr(rows, np.uint64); count = rows.shape[0]
         rows = _arr(rows, np.uint64, (count, self.H)); remaining = _arr(remaining, np.uint8, (count, self.N))
         self._ck(self.L.rp_set_roots(self.h, first, count, _ptr(rows), _ptr(remaining)))
+
+    def set_compact_rows(self, enable=True):
+        self._ck(self.L.rp_set_compact_rows(self.h, 1 if enable else 0))
 
     def set_step_cap(self, max_sims_per_step):
         self._ck(self.L.rp_set_step_cap(self.h, int(max_sims_per_step)))

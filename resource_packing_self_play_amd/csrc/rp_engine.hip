@@ -1452,27 +1452,30 @@ __global__ void k_items_generator(long long n, int N, int bin_w, int bin_h, cons
     for (int i = 0; i < N; ++i) { o[2 * i] = L[i][0]; o[2 * i + 1] = L[i][1]; }
 }
 
-// Compact list of the slots that wait for the evaluator, in slot order (deterministic).  One workgroup.
+// Compact list of the slots that wait for the evaluator, in slot order (deterministic).  One workgroup of 16 waves: wave w owns
+// the contiguous segment of ceil(G / 16) slots starting at w * segment and walks it 64 slots at a time (coalesced loads, ballot +
+// popcount): once to count, then -- after one barrier and the sum of the lower waves' counts -- once more to write rows in order.
 __global__ void __launch_bounds__(1024) k_compact(DP p) {
     __shared__ int wsum[16];
-    __shared__ int base;
-    const int tid = threadIdx.x, wid = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int start = 0; start < p.G; start += 1024) {
-        int g = start + tid;
-        bool flag = g < p.G && p.phase[g] == RP_PHASE_WAIT_EVAL;
-        u64 m = __ballot(flag);
-        if ((tid & 63) == 0) wsum[wid] = __popcll(m);
-        __syncthreads();
-        int off = base + __popcll(m & lanes_below());
-        for (int w = 0; w < wid; ++w) off += wsum[w];
-        if (flag) { p.eval_slot[off] = g; p.game_row[g] = off; }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; base += t; }
-        __syncthreads();
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int seg = (((p.G + 15) >> 4) + 63) & ~63, g0 = wid * seg, g1 = g0 + seg < p.G ? g0 + seg : p.G;
+    int cnt = 0;
+    for (int base = g0; base < g1; base += 64) {
+        const int g = base + lane;
+        cnt += __popcll(__ballot(g < g1 && p.phase[g] == RP_PHASE_WAIT_EVAL));
     }
-    if (tid == 0) *p.eval_count = base;
+    if (lane == 0) wsum[wid] = cnt;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    for (int base = g0; base < g1; base += 64) {
+        const int g = base + lane;
+        const bool flag = g < g1 && p.phase[g] == RP_PHASE_WAIT_EVAL;
+        const u64 m = __ballot(flag);
+        if (flag) { const int row = off + __popcll(m & lanes_below()); p.eval_slot[row] = g; p.game_row[g] = row; }
+        off += __popcll(m);
+    }
+    if (tid == 1023) *p.eval_count = off;
 }
 __global__ void k_reduce_counters(DP p) {  // totals over slots; one workgroup, thread k sums counter k % CNT_N over a slot stripe
     __shared__ u64 part[1024];
@@ -1855,9 +1858,12 @@ __device__ __forceinline__ void rs_conv(const float *img, const float *__restric
 }
 template <int NT>
 __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
-                                                           float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW) {
+                                                           float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
+                                                           const int *__restrict__ nrows_dev) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }  // only the first *nrows_dev rows hold leaves (compact rows)
+    if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE, MP = IMGW * PIX;
     int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
     float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
@@ -1977,9 +1983,12 @@ __device__ __forceinline__ void r32_conv(const float *img, const float4 *__restr
 // frag = [4][36][64] float4, bias = [4][32] in execution order; IMGW leaves per wave, IMGW * PIX <= 16 * NT.
 template <int NT>
 __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
-                                                       float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW) {
+                                                       float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
+                                                       const int *__restrict__ nrows_dev) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
+    if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * R32_STRIDE, MP = IMGW * PIX;
     int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
     float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
@@ -2071,10 +2080,13 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 // LDS staging copy of the convolution output that overwrites the (fully consumed) input images.  Output: pooled x, channels-last.
 template <int NT, int KS>
 __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
-                                                       float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats) {
+                                                       float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
+                                                       const int *__restrict__ nrows_dev) {
     constexpr int STRIDE = 4 * KS + 1, CIN = 4 * KS;
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
+    if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * STRIDE, MP = IMGW * PIX;
     int *ptab = (int *)rb_lds;
     float *img = rb_lds + 16 * NT + ((IMGW * (((S_h + 1) >> 1) * ((S_w + 1) >> 1)) + 3) & ~3) + (size_t)wv * wave_floats;
@@ -2157,6 +2169,8 @@ struct rp_ctx {
     u8 *pool_wh;
     int *pool_area, *pool_max_h;
     int64_t pool_cap;
+    int compact_rows = 0;             // rp_set_compact_rows: rp_search_step(ctx, NULL) lists the waiting slots on the device too
+    const int *nn_rows_dev = nullptr;  // row limit of the rp_nn_* stage kernels (eval_count) while compact rows are on
 };
 
 static std::string g_create_error;
@@ -2503,6 +2517,13 @@ extern "C" int rp_set_step_cap(rp_ctx *ctx, int32_t max_sims_per_step) {
     return RP_OK;
 }
 
+extern "C" int rp_set_compact_rows(rp_ctx *ctx, int32_t enable) {
+    if (!ctx) return RP_ERR_ARG;
+    ctx->compact_rows = enable ? 1 : 0;
+    ctx->nn_rows_dev = enable ? ctx->d.eval_count : nullptr;
+    return RP_OK;
+}
+
 extern "C" int rp_set_move_rule(rp_ctx *ctx, int32_t move_rule, int32_t onehot_examples) {
     if (!ctx || move_rule < RP_MOVE_EXTERNAL || move_rule > RP_MOVE_SAMPLE) return fail(ctx, RP_ERR_ARG, "rp_set_move_rule: bad argument");
     ctx->d.move_rule = move_rule;
@@ -2533,10 +2554,12 @@ extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
     DISPATCH(ctx, k_search, grid_for(d.G), d);
     // Without a count request nothing is synchronised and evaluator row b belongs to slot b (fixed shapes for graph capture);
     // with one, the waiting slots are listed in slot order and rows follow that list.
-    d.rows_identity = n_leaves_out ? 0 : 1;
-    if (n_leaves_out) {
+    d.rows_identity = (n_leaves_out || ctx->compact_rows) ? 0 : 1;
+    if (!d.rows_identity) {
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, ctx->stream, d);
         HIPCHK(ctx, hipGetLastError());
+    }
+    if (n_leaves_out) {
         int n = 0;
         HIPCHK(ctx, hipMemcpyAsync(&n, d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         int rc = check_device_error(ctx);  // synchronises
@@ -2671,7 +2694,7 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw); \
+        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
         break;
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
@@ -2711,7 +2734,7 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     {                                                                                                                                                \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL((k_convpool32<NT_, KS_>), grid, block, lds, ctx->stream, x_dev, (const float4 *)frag_dev, bias_dev, out_dev, (long long)B, (int)H,  \
-                           (int)W, imgw, (int)wf);                                                                                                   \
+                           (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                                 \
     }
     if (Cin == 16) {
         switch (nt) {
@@ -2749,7 +2772,7 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
     case NT_:                                                                                                                                       \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage32<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(k_resstage32<NT_>, grid, block, lds, ctx->stream, x_dev, (const float4 *)frag4_dev, bias4_dev, out_dev, out_relu_dev,    \
-                           (long long)B, (int)H, (int)W, imgw);                                                                                     \
+                           (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev);                                                                   \
         break;
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5)

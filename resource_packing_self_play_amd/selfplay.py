@@ -34,6 +34,7 @@ class _Group:
                                stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group,
                                vis_cap=owner.vis_cap, reclaim=1 if owner.reclaim else 0)
         self.eng.set_step_cap(owner.step_cap)
+        self.eng.set_compact_rows(owner.compact_rows)
         self.use_stem = owner.use_stem
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
             self.channels_last = owner.channels_last
@@ -72,7 +73,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, channels_last=True, resblock_kernel=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, compact_rows=True, channels_last=True, resblock_kernel=True, device=None):
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -83,6 +84,7 @@ class BatchedSelfPlay:
         self.G = int(games)
         self.move_rule, self.node_cap, self.edge_cap, self.step_cap = move_rule, node_cap, edge_cap, int(step_cap)
         self.reclaim, self.vis_cap = bool(reclaim), int(vis_cap)
+        self.compact_rows = bool(compact_rows)  # evaluator rows = the waiting slots only, listed on the device (rp_set_compact_rows)
         self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
         self.use_graph = use_graph
         self.use_stem = bool(use_stem)

@@ -447,3 +447,25 @@ def test_batched_selfplay_from_seeds_equals_host_generated_pool():
         assert len(out[0]) == len(seeds)
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+def test_batched_selfplay_compact_rows_changes_nothing():
+    """Evaluator rows = the waiting slots only (rp_set_compact_rows, the default of BatchedSelfPlay) against row b = slot b:
+    the same episodes, scores and counters -- a leaf's evaluation does not depend on its row or on its neighbours in the batch."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    from resource_packing_self_play_amd.selfplay import BatchedSelfPlay
+    d = np.load(os.path.join(GOLDEN, "nnet_c3_seed0.npz"))
+    game, net, args = gpu_wrapper(d)
+    args.numMCTSSims, args.cpuct, args.alpha = 10, 1, 0.75
+    seeds = np.arange(40, dtype=np.uint32) + 700
+    res = []
+    for compact in (True, False):
+        sp = BatchedSelfPlay(game, net, args, games=24, move_rule=_lib.MOVE_SAMPLE, seed=5, groups=1, compact_rows=compact)
+        sp.prepare()
+        out = sp.run_from_seeds(seeds, rewards_list=[0.9, 0.95, 1.0])
+        assert len(out[0]) == len(seeds)
+        st = out[4]
+        res.append(out[:4] + (np.array([st[k] for k in ("simulations", "expansions", "path_edges", "nodes")]),))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
