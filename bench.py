@@ -302,8 +302,8 @@ def main():
     # phases (single kernels, timed by events); the eagerly launched evaluator of the event-timed waves also carries the host's
     # launch gaps between its ~12 kernels and is only the fallback for --groups > 1
     eval_ms = per_wave[2]
-    if len(sp.groups) == 1 and tot["waves"] > 0:
-        eval_ms = dt * 1e3 / tot["waves"] - (per_wave[0] + per_wave[1] + per_wave[3])
+    if len(sp.groups) == 1 and waves > 0:  # this rank's own wave count
+        eval_ms = dt * 1e3 / waves - (per_wave[0] + per_wave[1] + per_wave[3])
     nn_tflops = (leaves_per_wave if sp.compact_rows else sp.groups[0].G) * (flops_leaf - stem_flops) / (eval_ms * 1e-3) / 1e12 if eval_ms > 0 else 0.0
     # roofline of the dominant kernel: the fused MFMA kernel with the largest measured time (HIP events around its launches in the
     # event-timed waves, other groups' kernels running beside it).  Algorithmic flops = 2 * 9 * Cin * Cout * pixels per convolution.
