@@ -189,6 +189,8 @@ int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), 
  *   out = x + conv1(relu(conv0(relu(x)) + b0)) + b1 ; out_relu = relu(out)   (BinpackingNNet.py:21-27)
  * rp_nn_pack_conv16 reorders a contiguous [16][16][3][3] weight into MFMA B-fragment order ([36][64] floats). */
 int rp_nn_pack_conv16(rp_ctx *ctx, const float *w_dev, float *frag_dev);
+/* Value head in one pass: out[b] = tanh(dot(z[b, :K], w) + bias[0])  (value_fc + tanh, BinpackingNNet.py:70,81); K a multiple of 4. */
+int rp_nn_value_head(rp_ctx *ctx, const float *z_dev, const float *w_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t K);
 int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, const float *bias0_dev, const float *frag1_dev, const float *bias1_dev,
                      float *out_dev, float *out_relu_dev /* may be NULL */, int64_t B, int32_t H, int32_t W);
 /* Both residual blocks of a 16-channel stage (ConvSequence.res_block0 then res_block1, BinpackingNNet.py:41-46) in one launch for

@@ -65,6 +65,7 @@ _SIGS = {
     "rp_stem_set_weights": (C.c_int, [_vp, _vp, _vp]),
     "rp_leaf_stem": (C.c_int, [_vp, _vp, _vp, _i64, _i32]),
     "rp_nn_pack_conv16": (C.c_int, [_vp, _vp, _vp]),
+    "rp_nn_value_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32]),
     "rp_nn_resblock16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_resstage16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "rp_nn_pack_conv32": (C.c_int, [_vp, _vp, _vp, _i32]),
@@ -299,6 +300,14 @@ class Engine:
         call()
         e1.record()
         sink.append((name, e0, e1))
+
+    def nn_value_head(self, z, weight, bias, out):
+        """out[b] = tanh(z[b] . weight + bias): z contiguous float32 [B, K], weight [1, K] or [K], bias [1], out [B] or [B, 1]."""
+        B, K = z.shape
+        if not (z.is_contiguous() and weight.is_contiguous() and out.is_contiguous()):
+            raise ValueError("nn_value_head needs contiguous tensors")
+        self._ck(self.L.rp_nn_value_head(self.h, C.c_void_p(z.data_ptr()), C.c_void_p(weight.data_ptr()), C.c_void_p(bias.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), B, K))
 
     def nn_pack_conv16(self, weight, frag):
         """weight: contiguous float32 [16, 16, 3, 3]; frag: float32 [36 * 64] buffer to fill (MFMA B-fragment order)."""

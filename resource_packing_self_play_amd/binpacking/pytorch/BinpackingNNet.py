@@ -90,6 +90,7 @@ class BinPackingNNet(nn.Module):
     # Both memory orders are kept: NCHW-flattened (c, h, w) and channels-last-flattened (h, w, c).
     DENSE_MAX_PIXELS = 9
     use_resblock_kernel = True
+    fused_linear_relu = hasattr(torch, "_addmm_activation")
 
     def _set_cached(self, key, value):
         if not hasattr(self, "_dense"):
@@ -223,12 +224,18 @@ class BinPackingNNet(nn.Module):
                 ops.nn_bias_residual(c1, blk.conv1.bias, x, out, out_r)
                 x, xr = out, out_r
         hw = getattr(self, "_dense", {}).get("hidden:cl") if cl else None
-        if cl and hw is not None:
-            z = F.linear(xr.permute(0, 2, 3, 1).reshape(xr.shape[0], -1), hw, None)
+        feats, wmat = (xr.permute(0, 2, 3, 1).reshape(xr.shape[0], -1), hw) if cl and hw is not None else (torch.flatten(xr, start_dim=1), self.hidden_fc.weight)
+        if self.fused_linear_relu:  # bias + ReLU as the GEMM's epilogue (hipBLASLt) instead of a second pass over z
+            z = torch._addmm_activation(self.hidden_fc.bias, feats, wmat.t())
         else:
-            z = F.linear(torch.flatten(xr, start_dim=1), self.hidden_fc.weight, None)
-        ops.nn_bias_relu(z.view(z.shape[0], z.shape[1], 1, 1), self.hidden_fc.bias)
-        return torch.softmax(self.logits_fc(z), dim=1), torch.tanh(self.value_fc(z))
+            z = F.linear(feats, wmat, None)
+            ops.nn_bias_relu(z.view(z.shape[0], z.shape[1], 1, 1), self.hidden_fc.bias)
+        if hasattr(ops, "nn_value_head") and z.shape[1] % 4 == 0:  # value_fc + tanh in one pass over z instead of a 1-column GEMM + 2 kernels
+            v = torch.empty((z.shape[0], 1), device=z.device, dtype=z.dtype)
+            ops.nn_value_head(z, self.value_fc.weight, self.value_fc.bias, v)
+        else:
+            v = torch.tanh(self.value_fc(z))
+        return torch.softmax(self.logits_fc(z), dim=1), v
 
     def forward_from_stem(self, y):
         """y = max_pool2d(conv_seqs[0].conv(x), 3, 2, 1), e.g. from the engine's rp_leaf_stem: the rest of the network."""

@@ -1164,11 +1164,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                 row_t v = __shfl(myrow, rr & 63);
                 rw[q] = (live && rr >= 0 && rr < p.H) ? v : (row_t)0;
             }
-            float acc[4][STEM_C];
+            float acc[4][STEM_C];  // outputs outside the image (odd sizes, idle lanes) start at -inf and stay there: the pool needs no selects
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const bool okj = live && ((j >> 1) ? rbok : true) && ((j & 1) ? xbok : true);
 #pragma unroll
-                for (int o = 0; o < STEM_C; ++o) acc[j][o] = bias[o];
+                for (int o = 0; o < STEM_C; ++o) acc[j][o] = okj ? bias[o] : -INFINITY;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
                 const int x = xa + (j & 1);
@@ -1208,16 +1210,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
             float best[STEM_C];
 #pragma unroll
             for (int o = 0; o < STEM_C; ++o) {
-                const float v00 = live ? acc[0][o] : -INFINITY, v01 = (live && xbok) ? acc[1][o] : -INFINITY;
-                const float v10 = rbok ? acc[2][o] : -INFINITY, v11 = (rbok && xbok) ? acc[3][o] : -INFINITY;
+                const float v00 = acc[0][o], v01 = acc[1][o], v10 = acc[2][o], v11 = acc[3][o];
                 const float fl = __shfl(fmaxf(v01, v11), (lane - 1) & 63);
                 const float fu = __shfl(fmaxf(v10, v11), (lane - p.Wp) & 63);
                 const float fc = __shfl(v11, (lane - p.Wp - 1) & 63);
-                float m = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
-                if (has_l) m = fmaxf(m, fl);
-                if (has_u) m = fmaxf(m, fu);
-                if (has_l && has_u) m = fmaxf(m, fc);
-                best[o] = m;
+                const float own = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+                const float nb = fmaxf(fmaxf(has_l ? fl : -INFINITY, has_u ? fu : -INFINITY), (has_l && has_u) ? fc : -INFINITY);
+                best[o] = fmaxf(own, nb);
             }
             const bool store = live && (pass == 0 || lr > 0);
             const int pp = pr * p.Wp + px;
@@ -1697,6 +1696,23 @@ __global__ void __launch_bounds__(256) k_nn_bias_pool_nhwc4(const float4 *__rest
     m.x += bi.x; m.y += bi.y; m.z += bi.z; m.w += bi.w;
     out[i] = m;
     if (out_relu) out_relu[i] = make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
+}
+
+// value head: out[b] = tanh(dot(z[b, :K], w) + bias)  (BinpackingNNet.py value_fc + tanh), one wave per row, 16-byte loads
+__global__ void __launch_bounds__(256) k_nn_value_head(const float4 *__restrict__ z, const float4 *__restrict__ w, const float *__restrict__ bias,
+                                                     float *__restrict__ out, long long B, int K4) {
+    const int lane = lane_id();
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float4 *zr = z + b * K4;
+    float acc = 0.f;
+    for (int k = lane; k < K4; k += 64) {
+        const float4 a = zr[k], c = w[k];
+        acc += a.x * c.x; acc += a.y * c.y; acc += a.z * c.z; acc += a.w * c.w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[b] = tanhf(acc + bias[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2649,6 +2665,15 @@ extern "C" int rp_nn_bias_pool(rp_ctx *ctx, const float *x_dev, const float *bia
     else
         hipLaunchKernelGGL(k_nn_bias_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x_dev, bias_dev, out_dev, out_relu_dev, n, (int)C, (int)H,
                            (int)W, Hp, Wp);
+    HIPCHK(ctx, hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_nn_value_head(rp_ctx *ctx, const float *z_dev, const float *w_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t K) {
+    if (!ctx || !z_dev || !w_dev || !bias_dev || !out_dev || B < 0 || K < 4 || K % 4) return fail(ctx, RP_ERR_ARG, "rp_nn_value_head: bad argument (K a multiple of 4)");
+    if (B == 0) return RP_OK;
+    hipLaunchKernelGGL(k_nn_value_head, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, ctx->stream, (const float4 *)z_dev, (const float4 *)w_dev, bias_dev, out_dev,
+                       (long long)B, (int)(K / 4));
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }
