@@ -196,7 +196,7 @@ def main():
     pool = a.pool or a.games
     node_cap = sims * (N + 1) + 2
     edge_cap, vis_cap = node_cap * a.edge_factor, int(node_cap * a.vis_factor)
-    if sims < 100:  # short profiling budgets: one open chunk per reachable level dominates the arena, not the entry count
+    if sims <= 100 or N <= 16:  # small configurations: one open chunk per reachable level dominates the arena, not the entry count
         edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * 4096), max(vis_cap, (min(sims, N) + 3) * 1024)
     sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=edge_cap, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
