@@ -2094,7 +2094,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 // Entry of a 32-channel stage (ConvSequence.conv + max_pool2d(3, 2, 1), BinpackingNNet.py:34,39-40): 3x3 convolution
 // Cin = 4 * KS -> 32 channels over the pixels of IMGW consecutive leaves, bias, then the 3x3 / stride-2 max-pool out of an
 // LDS staging copy of the convolution output that overwrites the (fully consumed) input images.  Output: pooled x, channels-last.
-template <int NT, int KS>
+template <int NT, int KS, bool LOOP>
 __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
                                                        const int *__restrict__ nrows_dev) {
@@ -2119,15 +2119,6 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     }
     for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;
     __syncthreads();
-    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
-    if (leaf0 >= B) return;
-    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
-    const float *xl = x + (size_t)leaf0 * PIX * CIN;
-    for (int e4 = lane; e4 < npix * KS; e4 += 64) {  // x (no ReLU in front of a stage's first convolution) into the padded images
-        float4 v = ((const float4 *)xl)[e4];
-        float *d = img + ptab[e4 / KS] + 4 * (e4 % KS);
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
     int abase[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -2135,12 +2126,41 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
         abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * STRIDE + (lane >> 4);
     }
     const int c = lane & 15;
-    f32x4 acc[NT][2];
-    wave_sync();
-    r32_conv<NT, KS>(img, frag, PW, abase, acc);
-    wave_sync();
-    {   // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows
-        const float ba = bias[c], bb = bias[16 + c];
+    const float ba = bias[c], bb = bias[16 + c];
+    const int PP = ((S_h + 1) >> 1) * ((S_w + 1) >> 1);
+    const int *pool = ptab + 16 * NT;  // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
+    const int cq = lane & 7;
+    // persistent waves: tables and zero borders once; the NEXT task's x is requested before this task's convolution and lands in
+    // registers while the matrix cores work
+    constexpr int XV = (NT * 16 * KS + 63) / 64;
+    const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
+    long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    float4 xv[XV];
+    if (leaf0 < B) {
+        const int np0 = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX;
+        const float4 *xl4 = (const float4 *)(x + (size_t)leaf0 * PIX * CIN);
+#pragma unroll
+        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np0 * KS ? xl4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    for (; leaf0 < B; leaf0 += stride_leaves) {
+        const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {  // x (no ReLU in front of a stage's first convolution) into the padded images
+            const int e4 = lane + 64 * k;
+            if (e4 < npix * KS) { float *d = img + ptab[e4 / KS] + 4 * (e4 % KS); d[0] = xv[k].x; d[1] = xv[k].y; d[2] = xv[k].z; d[3] = xv[k].w; }
+        }
+        const long long next0 = leaf0 + stride_leaves;
+        if (LOOP && next0 < B) {
+            const int np1 = (int)(B - next0 < IMGW ? B - next0 : IMGW) * PIX;
+            const float4 *xn4 = (const float4 *)(x + (size_t)next0 * PIX * CIN);
+#pragma unroll
+            for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np1 * KS ? xn4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+        f32x4 acc[NT][2];
+        wave_sync();
+        r32_conv<NT, KS>(img, frag, PW, abase, acc);
+        wave_sync();
+        // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -2148,25 +2168,28 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
                 int m = t * 16 + (lane >> 4) * 4 + q;
                 if (m < npix) { float *d = img + m * 36 + c; d[0] = acc[t][0][q] + ba; d[16] = acc[t][1][q] + bb; }
             }
-    }
-    wave_sync();
-    // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table
-    const int PP = ((S_h + 1) >> 1) * ((S_w + 1) >> 1);
-    const int *pool = ptab + 16 * NT;  // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
-    float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
-    const int cq = lane & 7;
-    for (int pq = lane >> 3; pq < nimg * PP; pq += 8) {
-        const int info = pool[pq], ctr = info & 0xFFFF;
-        const bool up = info & (1 << 16), down = info & (1 << 17), left = info & (1 << 18), right = info & (1 << 19);
-        const float4 *row = (const float4 *)(img + ctr * 36) + cq;
-        float4 m = row[0];
+        wave_sync();
+        // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table
+        float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
+        for (int pq = lane >> 3; pq < nimg * PP; pq += 8) {
+            const int info = pool[pq], ctr = info & 0xFFFF;
+            const bool up = info & (1 << 16), down = info & (1 << 17), left = info & (1 << 18), right = info & (1 << 19);
+            const float4 *row = (const float4 *)(img + ctr * 36) + cq;
+            float4 m = row[0];
 #define POOL_MAX(ok, off)                                                                                       \
-        if (ok) { const float4 v = row[(off) * 9]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-        POOL_MAX(left, -1) POOL_MAX(right, 1)
-        POOL_MAX(up, -S_w) POOL_MAX(up && left, -S_w - 1) POOL_MAX(up && right, -S_w + 1)
-        POOL_MAX(down, S_w) POOL_MAX(down && left, S_w - 1) POOL_MAX(down && right, S_w + 1)
+            if (ok) { const float4 v = row[(off) * 9]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
+            POOL_MAX(left, -1) POOL_MAX(right, 1)
+            POOL_MAX(up, -S_w) POOL_MAX(up && left, -S_w - 1) POOL_MAX(up && right, -S_w + 1)
+            POOL_MAX(down, S_w) POOL_MAX(down && left, S_w - 1) POOL_MAX(down && right, S_w + 1)
 #undef POOL_MAX
-        o4[pq * 8 + cq] = m;
+            o4[pq * 8 + cq] = m;
+        }
+        if (!LOOP) break;  // one task per wave: no back edge, nothing kept alive across tasks
+        wave_sync();
+        if (next0 < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
+            float4 *z4 = (float4 *)img;
+            for (int i = lane; i < (IMGW * IMG + 3) / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -2754,26 +2777,31 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     const size_t wf = wave_floats(imgw), lds = lds_bytes(imgw);
     if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: %dx%d image does not fit LDS", H, W);
     const long long tasks = (B + imgw - 1) / imgw;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-#define CP_LAUNCH(NT_, KS_)                                                                                                                          \
+    // persistent waves (two workgroups per CU, next task's input prefetched) once a wave has several tasks; below that one task per
+    // wave balances better (3 641 three-leaf tasks on 2 048 waves would take two rounds)
+    const bool persistent = Cin == 16 && tasks >= 4 * 2048;  // (the 32-channel form keeps 10 + 10 accumulators and 40 prefetch registers: slower as a loop)
+    const dim3 grid((unsigned)(persistent ? 2 * 256 : (tasks + 3) / 4)), block(256);
+#define CP_LAUNCH(NT_, KS_, LOOP_)                                                                                                                   \
     {                                                                                                                                                \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        hipLaunchKernelGGL((k_convpool32<NT_, KS_>), grid, block, lds, ctx->stream, x_dev, (const float4 *)frag_dev, bias_dev, out_dev, (long long)B, (int)H,  \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, KS_, LOOP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_convpool32<NT_, KS_, LOOP_>), grid, block, lds, ctx->stream, x_dev, (const float4 *)frag_dev, bias_dev, out_dev, (long long)B, (int)H, \
                            (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                                 \
     }
+#define CP_LAUNCH16(NT_) { if (persistent) CP_LAUNCH(NT_, 4, true) else CP_LAUNCH(NT_, 4, false) }
     if (Cin == 16) {
         switch (nt) {
-            case 1: CP_LAUNCH(1, 4) break; case 2: CP_LAUNCH(2, 4) break; case 3: CP_LAUNCH(3, 4) break; case 4: CP_LAUNCH(4, 4) break;
-            case 5: CP_LAUNCH(5, 4) break; case 6: CP_LAUNCH(6, 4) break; case 7: CP_LAUNCH(7, 4) break;
+            case 1: CP_LAUNCH16(1) break; case 2: CP_LAUNCH16(2) break; case 3: CP_LAUNCH16(3) break; case 4: CP_LAUNCH16(4) break;
+            case 5: CP_LAUNCH16(5) break; case 6: CP_LAUNCH16(6) break; case 7: CP_LAUNCH16(7) break;
             default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
         }
     } else {
         switch (nt) {
-            case 1: CP_LAUNCH(1, 8) break; case 2: CP_LAUNCH(2, 8) break; case 3: CP_LAUNCH(3, 8) break; case 4: CP_LAUNCH(4, 8) break;
-            case 5: CP_LAUNCH(5, 8) break;
+            case 1: CP_LAUNCH(1, 8, false) break; case 2: CP_LAUNCH(2, 8, false) break; case 3: CP_LAUNCH(3, 8, false) break; case 4: CP_LAUNCH(4, 8, false) break;
+            case 5: CP_LAUNCH(5, 8, false) break;
             default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
         }
     }
+#undef CP_LAUNCH16
 #undef CP_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
