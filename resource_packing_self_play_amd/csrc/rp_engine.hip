@@ -1872,7 +1872,7 @@ __device__ __forceinline__ void rs_conv(const float *img, const float *__restric
 #endif
     }
 }
-template <int NT>
+template <int NT, bool LOOP>
 __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                            float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
                                                            const int *__restrict__ nrows_dev) {
@@ -1889,15 +1889,17 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     }
     for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;  // borders (and missing leaves of the last group) stay zero
     __syncthreads();
-    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    // LOOP: persistent waves -- the next task's x is requested before this task's four convolutions and lands in registers meanwhile
+    constexpr int XV = NT;  // float4 per lane: 16 * NT pixels x 4 channel quads / 64 lanes
+    const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
+    long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
     if (leaf0 >= B) return;
-    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
-    const float *xl = x + (size_t)leaf0 * PIX * 16;
-    float *ol = out + (size_t)leaf0 * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 16 : nullptr;
-    for (int e4 = lane; e4 < npix * 4; e4 += 64) {  // relu(x) into the padded images, 16 bytes per lane
-        float4 v = ((const float4 *)xl)[e4];
-        float *d = img + ptab[e4 >> 2] + 4 * (e4 & 3);
-        d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
+    float4 xv[XV];
+    {
+        const int np0 = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX;
+        const float4 *xl4 = (const float4 *)(x + (size_t)leaf0 * PIX * 16);
+#pragma unroll
+        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np0 * 4 ? xl4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     int abase[NT];
 #pragma unroll
@@ -1907,6 +1909,25 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     }
     const int c = lane & 15;
     const float b0 = bias[c], b1 = bias[16 + c], b2 = bias[32 + c], b3 = bias[48 + c];
+    for (; leaf0 < B; leaf0 += stride_leaves) {
+    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
+    const float *xl = x + (size_t)leaf0 * PIX * 16;
+    float *ol = out + (size_t)leaf0 * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 16 : nullptr;
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {  // relu(x) into the padded images, 16 bytes per lane
+        const int e4 = lane + 64 * k;
+        if (e4 < npix * 4) {
+            float *d = img + ptab[e4 >> 2] + 4 * (e4 & 3);
+            d[0] = fmaxf(xv[k].x, 0.f); d[1] = fmaxf(xv[k].y, 0.f); d[2] = fmaxf(xv[k].z, 0.f); d[3] = fmaxf(xv[k].w, 0.f);
+        }
+    }
+    if (LOOP && leaf0 + stride_leaves < B) {
+        const long long next0 = leaf0 + stride_leaves;
+        const int np1 = (int)(B - next0 < IMGW ? B - next0 : IMGW) * PIX;
+        const float4 *xn4 = (const float4 *)(x + (size_t)next0 * PIX * 16);
+#pragma unroll
+        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np1 * 4 ? xn4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
     f32x4 acc[NT], y1[NT];
     wave_sync();
     rs_conv<NT>(img, frag, PW, abase, acc);                       // block 0, conv0
@@ -1944,6 +1965,9 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
                 if (orl) orl[m * 16 + c] = fmaxf(y, 0.f);
             }
         }
+    if (!LOOP) break;
+    wave_sync();
+    }
 }
 
 // The same for a 32-channel stage on small images (5x5 at the 20x20 board): M = the pixels of IMGW consecutive leaves (75 of
@@ -2738,11 +2762,20 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
     const int nt = (imgw * PIX + 15) / 16;
     const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * imgw * img_bytes;
     const long long tasks = (B + imgw - 1) / imgw;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+    // the persistent form (next task's x prefetched, as in k_convpool32) spills ~400 VGPRs here -- the kept skip operand and 28
+    // accumulators leave no room -- so it stays an experiment switch
+    static const bool allow_loop = getenv("RP_STAGE16_LOOP") != nullptr;
+    const bool persistent = allow_loop && tasks >= 4 * 2048;
+    const dim3 grid((unsigned)(persistent ? 2 * 256 : (tasks + 3) / 4)), block(256);
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k_resstage16<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
+        if (persistent) {                                                                                                                           \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_resstage16<NT_, true>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
+        } else {                                                                                                                                    \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_resstage16<NT_, false>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
+        }                                                                                                                                           \
         break;
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
