@@ -9,32 +9,101 @@ One STEP = one pass of the hot path over one batch of synthetic instances: a poo
 through `--games` concurrent game slots per GPU (search kernels + FP32 CNN evaluator, inputs resident in HBM).  Every
 rank plays its own pool (weak scaling, no data-path collective); value = episodes all ranks finished / max-over-ranks time.
 
+Wall budget.  A c3 pool is 32 768 whole episodes (~30 s), so `--steps 20 --warmup 5` would be ~14 minutes.  The run
+therefore works against a wall budget (`--budget`, default 380 s from process start, covering the CPU baseline, start-up,
+graph capture, a short warm-up pass and the pools): it plays whole pools back to back until K + W are done or the next pool
+would not fit, then counts the LAST min(K, done) pools as the timed steps (earlier ones as warm-up) and reports the ACTUAL
+`steps`, `warmup` and `ms_per_step`.  The named configuration never shrinks.  The JSON line is printed after every
+completed pool (last line wins), so a run that is cut short still leaves a parsable line.
+
+`--gpus N` without WORLD_SIZE in the environment starts the N ranks itself (children are spawned before anything touches
+the GPU; the parent never does).
+
 The JSON line also carries
-  roofline        the dominant phase (the CNN evaluator, FP32 MFMA bound) from HIP-event timings taken inside the timed region
+  roofline        the dominant kernel (FP32 MFMA bound) from HIP-event timings taken inside the timed region
   roofline_tree   the hand-written tree-walk kernels (k_search + k_commit, HBM bound): algorithmic bytes / event time
   cpu_baseline    the C oracle (oracle/rp_oracle.c) + the same CNN through PyTorch CPU, batch 1 per leaf as the
-                  reference does, on a bounded sample of the same workload, rank 0 only
+                  reference does, on a bounded sample of the same workload, rank 0 at N = 1 only
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
 
-import numpy as np
+T_PROCESS_START = time.time()
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward (SURVEY.md section 8d)
-    "c1": (10, 10, 8, 25, 2.18e6),
-    "c2": (10, 10, 8, 100, 2.18e6),
-    "c3": (20, 20, 32, 400, 10.01e6),
-    "c4": (20, 20, 32, 100, 10.01e6),
+CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward (SURVEY.md section 8d), default concurrent games per GPU
+    "c1": (10, 10, 8, 25, 2.18e6, 4096),
+    "c2": (10, 10, 8, 100, 2.18e6, 4096),
+    "c3": (20, 20, 32, 400, 10.01e6, 32768),
+    "c4": (20, 20, 32, 100, 10.01e6, 32768),
+    "c5": (50, 50, 128, 800, 133.4e6, 256),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
+DEFAULT_BUDGET_S = 380.0       # the driver kills the command at 600 s
+FINAL_RESERVE_S = 10.0         # standalone kernel timing + final line after the last pool
+ENGINE_SRC = os.path.join(ROOT, "resource_packing_self_play_amd", "csrc", "rp_engine.hip")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# budget planner (pure functions: tests/test_bench_contract.py runs them on the CPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def classify_pools(n_done, steps, warmup):
+    """(warm-up pools, timed pools) among n_done completed pools: timed steps come first, up to `steps`; what ran before
+    them counts as warm-up, at most `warmup`."""
+    warm = min(int(warmup), max(0, n_done - int(steps)))
+    return warm, n_done - warm
+
+
+def should_continue(elapsed_s, n_done, longest_pool_s, steps, warmup, budget_s, reserve_s=FINAL_RESERVE_S):
+    """Start another pool?  Always play one; stop at steps + warmup; otherwise only if a pool 10 % longer than the longest
+    so far still ends inside the budget with the finalisation reserve left."""
+    if n_done == 0:
+        return True
+    if n_done >= int(steps) + int(warmup):
+        return False
+    return elapsed_s + 1.1 * longest_pool_s + reserve_s <= budget_s
+
+
+def simulate_plan(startup_s, pool_s, steps, warmup, budget_s=DEFAULT_BUDGET_S, reserve_s=FINAL_RESERVE_S):
+    """Planned wall time of a run whose start-up (CPU baseline, imports, capture, warm-up pass) takes startup_s and whose
+    pools take pool_s each.  Returns (pools played, warm-up pools, timed pools, wall seconds)."""
+    t, n = float(startup_s), 0
+    while should_continue(t, n, pool_s, steps, warmup, budget_s, reserve_s):
+        t += pool_s
+        n += 1
+    warm, timed = classify_pools(n, steps, warmup)
+    return n, warm, timed, t + reserve_s
+
+
+def engine_hash():
+    try:
+        return hashlib.sha256(open(ENGINE_SRC, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.py).  PMC counters cannot be read
+    from inside the run, so the file carries the SHA-256 of the rp_engine.hip it was measured on; a different engine
+    source means the figures are stale and `traffic` is reported as null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_traffic.json missing"
+    rec = json.load(open(path))
+    if rec.get("engine_sha256") != engine_hash():
+        return None, "profiles/pmc_traffic.json was measured on another rp_engine.hip (hash mismatch): stale, not reported"
+    return rec, None
 
 
 def make_instances(W, H, N, count, base_seed):
@@ -70,7 +139,7 @@ def cpu_worker(cfg, episodes, seed0, budget_s):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     from resource_packing_self_play_amd.binpacking.pytorch.BinpackingNNet import BinPackingNNet
-    W, H, N, sims, _ = CONFIGS[cfg]
+    W, H, N, sims = CONFIGS[cfg][:4]
 
     class G:
         def getBoardSize(self): return (H, W)
@@ -128,7 +197,7 @@ def run_cpu_baseline(cfg, budget_s):
     wall = max(o["seconds"] for o in outs)
     eps = sum(o["episodes"] for o in outs)
     exp = sum(o["expansions"] for o in outs)
-    W, H, N, sims, _ = CONFIGS[cfg]
+    W, H, N, sims = CONFIGS[cfg][:4]
     return {"value": eps / wall, "unit": "episodes/s", "cores": len(outs), "kind": "port",
             "expansions_per_s": exp / wall, "per_core_episodes_per_s": eps / wall / len(outs),
             "sample": "%d whole episodes of the bench workload (%dx%d, %d items, %d sims/move, seeds 100+), C oracle search + "
@@ -137,13 +206,154 @@ def run_cpu_baseline(cfg, budget_s):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def main():
+# --gpus N without a launcher: start the ranks ourselves, before anything in this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """One child process per rank with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Rank 0's stdout
+    is this process's stdout (it prints the JSON line).  Returns the first non-zero exit code, or 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RP_BENCH_T0=repr(T_PROCESS_START))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    if rc != 0:  # do not leave ranks waiting in a collective for a rank that died
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the JSON line (pure: tests build it from synthetic statistics)
+# ---------------------------------------------------------------------------------------------------------------------
+def key_bytes(W, H, N):
+    return (8 if W > 32 else 4) * H + (N + 31) // 32 * 4
+
+
+def stage_kernel_flops(W, H):
+    """Algorithmic flops per leaf of the fused evaluator kernels: 2 * 9 * Cin * Cout * pixels per convolution."""
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    Hs2, Ws2 = (Hs + 1) // 2, (Ws + 1) // 2
+    Hs3, Ws3 = (Hs2 + 1) // 2, (Ws2 + 1) // 2
+    return {"k_resstage16 %dx%d" % (Hs, Ws): 4 * 2 * 9 * 16 * 16 * Hs * Ws,
+            "k_convpool32 16->32 %dx%d" % (Hs, Ws): 2 * 9 * 16 * 32 * Hs * Ws,
+            "k_resstage32 %dx%d" % (Hs2, Ws2): 4 * 2 * 9 * 32 * 32 * Hs2 * Ws2,
+            "k_convpool32 32->32 %dx%d" % (Hs2, Ws2): 2 * 9 * 32 * 32 * Hs2 * Ws2,
+            "k_resstage32 %dx%d" % (Hs3, Ws3): 4 * 2 * 9 * 32 * 32 * Hs3 * Ws3}
+
+
+def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps, warmup, requested, dt, tot, waves_rank0, groups, slots_group0,
+                 use_stem, compact_rows, per_wave, kernel_ms, solo, cpu_base, mean_score, mean_moves, extra):
+    """tot: counters summed over ranks for the timed pools (+ 'waves'); per_wave: mean ms per wave of (search, stem/planes,
+    evaluator, commit) from the event-timed waves; kernel_ms: {kernel label: mean ms per launch} from HIP events."""
+    episodes = tot["episodes"]
+    K, A = key_bytes(W, H, N), W * N
+    # algorithmic bytes of the tree walk with THIS layout (DESIGN.md section 4).  Per selected node: 32 B header, 4 B prior per
+    # unvisited legal move, 22 B per visited entry (idx, N, Q, P), 6 B (child, action); 26 B per visited entry created;
+    # per backed-up edge 32 B (Q, N, Ns read + write); per expansion: key write + compare 2K, one 512 B probe window,
+    # 32 B header write, 2 B action write per legal move (k_search) and, in k_commit, the 64 B header read-modify-write,
+    # the evaluator's 4A + 4 B output, 2 B action read + 4 B prior write per legal move.
+    sel_bytes = 38.0 * tot["path_edges"] + 4.0 * (tot["sum_valid_select"] - tot["sum_visited_select"]) + 22.0 * tot["sum_visited_select"] \
+        + 26.0 * tot["visited_new"]
+    bak_bytes = 32.0 * tot["path_edges"]
+    exp_bytes = tot["expansions"] * (2 * K + 512 + 32 + 64 + 4 * A + 4) + 8.0 * tot["sum_valid_leaf"]
+    tree_bytes = sel_bytes + bak_bytes + exp_bytes
+    tree_ms = per_wave[0] + per_wave[3]
+    launches = max(tot["waves"], 1) * groups  # one k_search / evaluator / k_commit launch per group and wave
+    tree_bytes_per_wave = tree_bytes / launches
+    leaves_per_wave = tot["expansions"] / launches
+    stem_flops = 2 * 9 * (N + 1) * 16 * H * W if use_stem else 0  # first convolution: table sums in k_leaf_stem, not matrix-core work
+    # evaluator time per wave: with one slot group the waves run back to back, so it is the wall time per wave minus the three engine
+    # phases (single kernels, timed by events); the eagerly launched evaluator of the event-timed waves also carries the host's
+    # launch gaps between its kernels and is only the fallback for --groups > 1
+    eval_ms = per_wave[2]
+    if groups == 1 and waves_rank0 > 0:
+        eval_ms = dt * 1e3 / waves_rank0 - (per_wave[0] + per_wave[1] + per_wave[3])
+    rows = leaves_per_wave if compact_rows else slots_group0
+    nn_tflops = rows * (flops_leaf - stem_flops) / (eval_ms * 1e-3) / 1e12 if eval_ms > 0 else 0.0
+    kflops = stage_kernel_flops(W, H)
+    Hs, Ws = (H + 1) // 2, (W + 1) // 2
+    kbytes = {"k_resstage16 %dx%d" % (Hs, Ws): 2 * 4 * 16 * Hs * Ws}  # x in, result out, per leaf
+    pmc, pmc_note = load_pmc_traffic()
+    roof = None
+    timed = {k: v for k, v in kernel_ms.items() if k in kflops}
+    if timed:
+        kname = max(timed, key=lambda k: timed[k][0])
+        kms, klaunches = timed[kname]
+        ach = rows * kflops[kname] / (kms * 1e-3) / 1e12
+        traffic = None
+        if pmc is not None:
+            rec = pmc.get("kernels", {}).get(kname.split(" ")[0])
+            if rec and rec.get("leaves_per_launch"):  # the PMC passes cover the pool's first waves (every slot waiting): scale per leaf
+                traffic = rec["hbm_bytes_per_launch"] / rec["leaves_per_launch"] * rows
+        roof = {"kernel": kname + " (FP32 MFMA, own HIP kernel)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": pmc_note, "flops_per_launch": rows * kflops[kname],
+                "ms_per_launch": kms, "leaves_per_launch": rows, "launches_timed": klaunches,
+                "algorithmic_bytes_per_launch": rows * kbytes.get(kname, 0) or None}
+        if solo:
+            roof["standalone"] = solo
+            roof["note"] = "achieved/frac: HIP events around the kernel's launches inside the timed region; standalone: the same launch on all slot rows after the timed region"
+    if roof is None:
+        roof = {"kernel": "CNN evaluator (all kernels of one forward over the slot batch)", "bound": "mfma", "achieved": nn_tflops,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+    tree_traffic = None
+    if pmc is not None and all(k in pmc.get("kernels", {}) for k in ("k_search", "k_commit")):
+        ks = pmc["kernels"]
+        tree_traffic = sum(ks[k]["hbm_bytes_per_launch"] / ks[k]["leaves_per_launch"] for k in ("k_search", "k_commit")) * rows
+    tree_gbs = tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+    out = {
+        "metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": episodes / dt, "unit": "episodes/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / max(steps, 1) * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64 PUCT / f32 Q + CNN, u32 bit-board", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d bin, %d items, %d MCTS sims/move, %d concurrent games per GPU, pool of %d instances per step per GPU"
+                               % (cfg_name, W, H, N, sims, games, pool), "evaluator": "BinPackingNNet FP32 via PyTorch-ROCm, torch.manual_seed(0) init",
+                   "move_rule": "sample ~ visit counts", "parallelism": "dp%d (episodes sharded, no data-path collective)" % world},
+        "requested": requested,
+        "expansions_per_s": tot["expansions"] / dt, "simulations_per_s": tot["simulations"] / dt, "episodes": episodes,
+        "waves": tot["waves"], "mean_moves_per_episode": mean_moves, "mean_score": mean_score,
+        "tree_stats": {"path_edges_per_sim": tot["path_edges"] / max(tot["simulations"], 1),
+                       "valid_per_selected_node": tot["sum_valid_select"] / max(tot["path_edges"], 1),
+                       "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
+                       "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
+                       "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
+        "phase_ms_per_launch": {"search": per_wave[0], "leaf_stem" if use_stem else "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
+        "roofline": roof,
+        "roofline_evaluator": {"kernel": "whole CNN evaluator after the stem (fused MFMA kernels + heads) over the slot batch", "bound": "mfma",
+                               "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": None, "flops_per_leaf": flops_leaf - stem_flops, "flops_per_leaf_with_first_conv": flops_leaf,
+                               "leaves_per_launch": rows, "ms_per_launch": eval_ms},
+        "kernel_ms_per_launch": {k: v[0] for k, v in sorted(kernel_ms.items())},
+        "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm", "achieved": tree_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": tree_gbs / PEAK_HBM_GBS, "traffic": tree_traffic,
+                          "bytes_per_launch": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
+                          "leaves_per_launch": leaves_per_wave, "slots_per_launch": slots_group0},
+        "cpu_baseline": cpu_base,
+    }
+    out.update(extra)
+    if cpu_base:
+        out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("RP_BENCH_BUDGET_S", DEFAULT_BUDGET_S)),
+                    help="wall budget in seconds from process start; whole pools are played while the next one fits")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--games", type=int, default=32768, help="concurrent game slots per GPU (BASELINE configs[2]: 32k concurrent games)")
+    ap.add_argument("--games", type=int, default=0, help="concurrent game slots per GPU (default: the configuration's, 32 768 for c3)")
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--edge-factor", type=int, default=24, help="legal-move arena = node arena x this (6 B per entry)")
@@ -155,50 +365,86 @@ def main():
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-fuse", action="store_true", help="leave bias / ReLU / skip / pool to PyTorch's own element-wise kernels")
     ap.add_argument("--no-dense", action="store_true", help="keep <= 3x3-image convolutions on MIOpen instead of one GEMM each")
-    ap.add_argument("--no-resblock", action="store_true", help="16-channel residual blocks through MIOpen + fused element-wise kernels instead of rp_nn_resblock16")
+    ap.add_argument("--no-resblock", action="store_true", help="16-channel residual blocks through MIOpen + fused element-wise kernels instead of the stage kernels")
     ap.add_argument("--nchw", action="store_true", help="keep the evaluator's activations NCHW instead of channels-last")
     ap.add_argument("--no-compact", action="store_true", help="evaluator row b = slot b (every slot costs convolution work) instead of the waiting slots only")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--warm-waves", type=int, default=96, help="waves of the short warm-up pass before the first pool")
     ap.add_argument("--event-every", type=int, default=16, help="take per-phase HIP-event timings every n-th wave")
     ap.add_argument("--profile-waves", type=int, default=0, help="profiling aid: stop after this many waves per group and print no metric")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (ranks, process group, collectives, JSON line) without the GPU work")
     ap.add_argument("--cpu-worker", default=None)
     ap.add_argument("--cpu-episodes", type=int, default=1)
     ap.add_argument("--cpu-seed", type=int, default=100)
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker, a.cpu_episodes, a.cpu_seed, a.cpu_budget)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become one (this process never touches the GPU)
+        sys.exit(spawn_ranks(a.gpus, argv))
 
-    W, H, N, sims, flops_leaf = CONFIGS[a.config]
+    t_start = float(os.environ.get("RP_BENCH_T0", T_PROCESS_START))
+    W, H, N, sims, flops_leaf, games_default = CONFIGS[a.config]
     sims = a.sims or sims
+    games = a.games or games_default
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_base = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.sims:  # N = 1 only, the configured workload only; before this process touches the GPU
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.sims and not a.dry_run:  # N = 1 only, before this process touches the GPU
         cpu_base = run_cpu_baseline(a.config, a.cpu_budget)
+    t_cpu_done = time.time()
 
     import torch
     import torch.distributed as dist
-    from resource_packing_self_play_amd import _lib
     from resource_packing_self_play_amd import distributed as rdist
+    rank, world, local = rdist.init_from_env()
+    joined = dist.get_world_size() if dist.is_initialized() else 1
+    host_collectives = dist.is_initialized() and dist.get_backend() == "gloo"
+    requested = {"gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "budget_s": a.budget}
+
+    def allreduce(vals, op):
+        dev_ = torch.device("cpu") if (a.dry_run or host_collectives) else torch.device("cuda", local)
+        t = torch.tensor(list(vals), dtype=torch.float64, device=dev_)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return t.tolist()
+
+    if a.dry_run:
+        if world > 1:
+            dist.barrier()
+        dt = allreduce([1.0 + 0.01 * rank], dist.ReduceOp.MAX)[0]
+        ranks = allreduce([1.0], dist.ReduceOp.SUM)[0]
+        if rank == 0:
+            print(json.dumps({"metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": None, "unit": "episodes/s",
+                              "n_gpus": joined, "ranks_joined": int(ranks), "steps": 0, "warmup": 0, "ms_per_step": dt * 1e3, "dry_run": True,
+                              "requested": requested, "backend": dist.get_backend() if dist.is_initialized() else None}), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
+
+    from resource_packing_self_play_amd import _lib
     from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame
     from resource_packing_self_play_amd.binpacking.pytorch.NNet import NNetWrapper
     from resource_packing_self_play_amd.selfplay import BatchedSelfPlay
 
-    rank, world, local = rdist.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     game = BinPackingGame(W, H, N, 1)
     args = Args(numMCTSSims=sims, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=64)
     torch.manual_seed(0)
     nnet = NNetWrapper(game, args)
-    pool = a.pool or a.games
+    pool = a.pool or games
     node_cap = sims * (N + 1) + 2
     edge_cap, vis_cap = node_cap * a.edge_factor, int(node_cap * a.vis_factor)
     if sims <= 100 or N <= 16:  # small configurations: one open chunk per reachable level dominates the arena, not the entry count
         edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * 4096), max(vis_cap, (min(sims, N) + 3) * 1024)
-    sp = BatchedSelfPlay(game, nnet, args, games=a.games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
+    sp = BatchedSelfPlay(game, nnet, args, games=games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=edge_cap, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
                          reclaim=not a.no_reclaim, vis_cap=vis_cap, compact_rows=not a.no_compact, channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
     sp.prepare()  # evaluator warm-up + capture of the whole wave into one HIP graph, outside every timed region
@@ -208,11 +454,11 @@ def main():
     phase_n = 0
     kev, kernel_ms = [], {}
 
-    def play_pool(step_idx, timed):
+    def play_pool(pool_idx, timed, max_waves=0):
         nonlocal phase_ms, phase_n
         # instances = ItemsGenerator.items_generator(seed), seeds 100 + index as in main_bpp.py:33, generated on the device
         # (bit-identical to the host generator; 32 768 instances through the Python generator would cost seconds of host time)
-        sp.start_from_seeds(np.arange(pool, dtype=np.uint32) + np.uint32(100 + (step_idx * world + rank) * pool), buf, first_id=0)
+        sp.start_from_seeds(np.arange(pool, dtype=np.uint32) + np.uint32(100 + (pool_idx * world + rank) * pool), buf, first_id=0)
         waves = 0
         pending = []
         g0 = sp.groups[0]
@@ -234,6 +480,9 @@ def main():
                 else:
                     sp.step()
                 waves += 1
+            if max_waves and waves >= max_waves:
+                torch.cuda.synchronize(dev)
+                return waves, 0.0, 0.0
             if sp.active() == 0:
                 break
             if a.profile_waves and waves >= a.profile_waves:
@@ -256,138 +505,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for w in range(a.warmup):
-        play_pool(w, False)
+    # short warm-up pass: the first waves of a pool (every slot waits for the evaluator: the heaviest waves) through the captured
+    # graph and through the event-timed eager path, then the pool is abandoned (rp_begin_pool restarts every slot)
+    if a.warm_waves > 0 and not a.profile_waves:
+        play_pool(0, True, max_waves=a.warm_waves)
+        sp.pop_finished()
+        phase_ms[:] = 0; phase_n = 0; del kev[:]; kernel_ms.clear()
     sp.counters(reset=True)
+    names = list(_lib.COUNTER_NAMES)
     barrier()
-    t0 = time.time()
-    waves = 0
-    for k in range(a.steps):
-        wv, mean_score, mean_moves = play_pool(a.warmup + k, True)
-        waves += wv
-    barrier()
-    dt = time.time() - t0
-    c = sp.counters()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(c[k]) for k in _lib.COUNTER_NAMES] + [float(waves)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
-    tot = dict(zip(list(_lib.COUNTER_NAMES) + ["waves"], tot.tolist()))
-    if rank != 0:
-        return
-    episodes = tot["episodes"]
-    K = 4 * H + (N + 31) // 32 * 4  # key bytes (32-bit rows for W <= 32)
-    if W > 32:
-        K = 8 * H + (N + 31) // 32 * 4
-    A = W * N
-    # algorithmic bytes of the tree walk with THIS layout.  Per selected node: 32 B header, 4 B prior per
-    # unvisited legal move, 22 B per visited entry (idx, N, Q, P), 6 B (child, action); 26 B per visited entry created;
-    # per backed-up edge 32 B (Q, N, Ns read + write); per expansion: key write + compare 2K, one 512 B probe window,
-    # 32 B header write, 2 B action write per legal move (k_search) and, in k_commit, the 64 B header read-modify-write,
-    # the evaluator's 4A + 4 B output, 2 B action read + 4 B prior write per legal move.
-    sel_bytes = 38.0 * tot["path_edges"] + 4.0 * (tot["sum_valid_select"] - tot["sum_visited_select"]) + 22.0 * tot["sum_visited_select"] \
-        + 26.0 * tot["visited_new"]
-    bak_bytes = 32.0 * tot["path_edges"]
-    exp_bytes = tot["expansions"] * (2 * K + 512 + 32 + 64 + 4 * A + 4) + 8.0 * tot["sum_valid_leaf"]
-    tree_bytes = sel_bytes + bak_bytes + exp_bytes
-    per_wave = phase_ms / max(phase_n, 1)  # ms per wave: search, planes, evaluator, commit
-    tree_ms = per_wave[0] + per_wave[3]
-    launches = max(tot["waves"], 1) * len(sp.groups)  # one k_search / evaluator / k_commit launch per group and wave
-    tree_bytes_per_wave = tree_bytes / launches
-    leaves_per_wave = tot["expansions"] / launches
-    stem_flops = 2 * 9 * (N + 1) * 16 * H * W if sp.use_stem else 0  # first convolution: replaced by table sums in k_leaf_stem, not matrix-core work
-    # evaluator time per wave: with one slot group the waves run back to back, so it is the wall time per wave minus the three engine
-    # phases (single kernels, timed by events); the eagerly launched evaluator of the event-timed waves also carries the host's
-    # launch gaps between its ~12 kernels and is only the fallback for --groups > 1
-    eval_ms = per_wave[2]
-    if len(sp.groups) == 1 and waves > 0:  # this rank's own wave count
-        eval_ms = dt * 1e3 / waves - (per_wave[0] + per_wave[1] + per_wave[3])
-    nn_tflops = (leaves_per_wave if sp.compact_rows else sp.groups[0].G) * (flops_leaf - stem_flops) / (eval_ms * 1e-3) / 1e12 if eval_ms > 0 else 0.0
-    # roofline of the dominant kernel: the fused MFMA kernel with the largest measured time (HIP events around its launches in the
-    # event-timed waves, other groups' kernels running beside it).  Algorithmic flops = 2 * 9 * Cin * Cout * pixels per convolution.
-    Gs = sp.groups[0].G
-    Hs, Ws = (H + 1) // 2, (W + 1) // 2
-    kflops = {"k_resstage16 %dx%d" % (Hs, Ws): 4 * 2 * 9 * 16 * 16 * Hs * Ws,
-              "k_convpool32 16->32 %dx%d" % (Hs, Ws): 2 * 9 * 16 * 32 * Hs * Ws}
-    Hs2, Ws2 = (Hs + 1) // 2, (Ws + 1) // 2
-    kflops["k_resstage32 %dx%d" % (Hs2, Ws2)] = 4 * 2 * 9 * 32 * 32 * Hs2 * Ws2
-    kflops["k_convpool32 32->32 %dx%d" % (Hs2, Ws2)] = 2 * 9 * 32 * 32 * Hs2 * Ws2
-    Hs3, Ws3 = (Hs2 + 1) // 2, (Ws2 + 1) // 2
-    kflops["k_resstage32 %dx%d" % (Hs3, Ws3)] = 4 * 2 * 9 * 32 * 32 * Hs3 * Ws3
-    kbytes = {"k_resstage16 %dx%d" % (Hs, Ws): 2 * 4 * 16 * Hs * Ws}  # x in, result out, per leaf
-    roof = None
-    if kernel_ms:
-        kname = max((k for k in kernel_ms if k in kflops), key=lambda k: np.mean(kernel_ms[k]), default=None)
-        if kname is not None:
-            kms = float(np.mean(kernel_ms[kname]))
-            # with compact rows the kernel processes the waiting leaves only: mean leaves per launch from the engine's counters
-            Ls = leaves_per_wave if sp.compact_rows else Gs
-            ach = Ls * kflops[kname] / (kms * 1e-3) / 1e12
-            traffic = None
-            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-            if os.path.exists(tfile):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled, MI355X_MICROARCH.md)
-                rec = json.load(open(tfile)).get(kname.split(" ")[0])
-                if rec and rec.get("leaves_per_launch"):  # the PMC passes cover the pool's first waves (every slot waiting): scale per leaf
-                    traffic = rec["hbm_bytes_per_launch"] / rec["leaves_per_launch"] * Ls
-            roof = {"kernel": kname + " (FP32 MFMA, own HIP kernel)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "flops_per_launch": Ls * kflops[kname], "ms_per_launch": kms,
-                    "leaves_per_launch": Ls, "launches_timed": len(kernel_ms[kname]), "algorithmic_bytes_per_launch": Ls * kbytes.get(kname, 0) or None}
-    if roof is not None and roof["kernel"].startswith("k_resstage16") and "stagefrag:0" in getattr(sp.nnet.nnet, "_dense", {}):
-        # the same kernel on the same tensors with the GPU to itself (after the timed region): what the co-scheduled figure above
-        # costs in isolation; profiles/ holds the rocprofv3 summaries of both situations
-        g0 = sp.groups[0]
-        dn = sp.nnet.nnet._dense
-        g0.eng.set_compact_rows(False)  # all Gs rows of the (stale) stem buffer: the row limit would read 0 after the last episode
-        with torch.cuda.stream(g0.stream):
-            o = torch.empty_like(g0.stem)
-            g0.eng.kernel_events = solo = []
-            for _ in range(24):
-                g0.eng.nn_resstage16(g0.stem, dn["stagefrag:0"], dn["stagebias:0"], o, None)
-            g0.eng.kernel_events = None
-        torch.cuda.synchronize(dev)
-        solo_ms = float(np.mean([e0.elapsed_time(e1) for _, e0, e1 in solo[4:]]))
-        g0.eng.set_compact_rows(sp.compact_rows)
-        solo_fl = Gs * kflops[kname]
-        roof["standalone"] = {"ms_per_launch": solo_ms, "leaves_per_launch": Gs, "achieved": solo_fl / (solo_ms * 1e-3) / 1e12,
-                              "frac": solo_fl / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-        roof["note"] = "achieved/frac: HIP events around the kernel's launches inside the timed region (with --groups > 1 other groups' kernels share the GPU); standalone: the same launch after the timed region"
-    if roof is None:
-        roof = {"kernel": "CNN evaluator (all kernels of one forward over the slot batch)", "bound": "mfma", "achieved": nn_tflops,
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
-    out = {
-        "metric": "self-play episodes/sec (with MCTS node expansions/sec alongside)", "value": episodes / dt, "unit": "episodes/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64 PUCT / f32 Q + CNN, u32 bit-board", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d bin, %d items, %d MCTS sims/move, %d concurrent games per GPU, pool of %d instances per step per GPU"
-                               % (a.config, W, H, N, sims, a.games, pool), "evaluator": "BinPackingNNet FP32 via PyTorch-ROCm, torch.manual_seed(0) init",
-                   "move_rule": "sample ~ visit counts", "parallelism": "dp%d (episodes sharded, no data-path collective)" % world},
-        "expansions_per_s": tot["expansions"] / dt, "simulations_per_s": tot["simulations"] / dt, "episodes": episodes,
-        "waves": tot["waves"], "mean_moves_per_episode": mean_moves, "mean_score": mean_score,
-        "tree_stats": {"path_edges_per_sim": tot["path_edges"] / max(tot["simulations"], 1),
-                       "valid_per_selected_node": tot["sum_valid_select"] / max(tot["path_edges"], 1),
-                       "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
-                       "expansions_per_sim": tot["expansions"] / max(tot["simulations"], 1),
-                       "transposition_links": tot["transposition_links"], "nodes": tot["nodes"]},
-        "phase_ms_per_launch": {"search": per_wave[0], "leaf_stem" if sp.use_stem else "leaf_planes": per_wave[1], "evaluator": per_wave[2], "commit": per_wave[3]},
-        "roofline": roof,
-        "roofline_evaluator": {"kernel": "whole CNN evaluator after the stem (fused MFMA kernels + hipBLASLt heads) over the slot batch", "bound": "mfma",
-                               "achieved": nn_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": nn_tflops / PEAK_FP32_MFMA_TFLOPS,
-                               "traffic": None, "flops_per_leaf": flops_leaf - stem_flops, "flops_per_leaf_with_first_conv": flops_leaf,
-                               "leaves_per_launch": leaves_per_wave if sp.compact_rows else sp.groups[0].G, "ms_per_launch": eval_ms},
-        "kernel_ms_per_launch": {k: float(np.mean(v)) for k, v in sorted(kernel_ms.items())},
-        "roofline_tree": {"kernel": "k_search + k_commit", "bound": "hbm",
-                          "achieved": tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": (tree_bytes_per_wave / (tree_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if tree_ms > 0 else 0.0, "traffic": None,
-                          "bytes_per_launch": tree_bytes_per_wave, "bytes_per_sim": tree_bytes / max(tot["simulations"], 1),
-                          "leaves_per_launch": leaves_per_wave, "slots_per_launch": sp.groups[0].G},
-        "cpu_baseline": cpu_base,
-        "device_bytes": sp.device_bytes, "arena_peak_per_slot": sp.arena_peak(),
-    }
-    if cpu_base:
-        out["speedup_vs_cpu_baseline"] = out["value"] / cpu_base["value"]
-    print(json.dumps(out))
+    bounds = [time.time()]       # pool boundaries on this rank's clock (after barrier + synchronize)
+    snaps = [np.zeros(len(names) + 1)]  # cumulative counters (+ waves) of this rank at every boundary
+    scores = []
+    n_done, cum_waves = 0, 0
+    solo = None
+    while True:
+        wv, mean_score, mean_moves = play_pool(n_done, True)
+        barrier()
+        bounds.append(time.time())
+        c = sp.counters()
+        cum_waves += wv
+        snaps.append(np.array([float(c[k]) for k in names] + [float(cum_waves)]))
+        scores.append((mean_score, mean_moves))
+        n_done += 1
+        longest = max(b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:]))
+        go = should_continue(time.time() - t_start, n_done, longest, a.steps, a.warmup, a.budget)
+        go = allreduce([1.0 if go else 0.0], dist.ReduceOp.MIN)[0] > 0.5 if world > 1 else go  # every rank must agree
+        if not go and n_done > 0 and solo is None and "stagefrag:0" in getattr(sp.nnet.nnet, "_dense", {}) and (W + 1) // 2 * ((H + 1) // 2) <= 128:
+            # the dominant stage kernel on ALL slot rows with the GPU to itself (after the timed region)
+            g0 = sp.groups[0]
+            dn = sp.nnet.nnet._dense
+            g0.eng.set_compact_rows(False)  # the row limit would read 0 after the last episode
+            with torch.cuda.stream(g0.stream):
+                o = torch.empty_like(g0.stem)
+                g0.eng.kernel_events = solo_ev = []
+                for _ in range(24):
+                    g0.eng.nn_resstage16(g0.stem, dn["stagefrag:0"], dn["stagebias:0"], o, None)
+                g0.eng.kernel_events = None
+            torch.cuda.synchronize(dev)
+            solo_ms = float(np.mean([e0.elapsed_time(e1) for _, e0, e1 in solo_ev[4:]]))
+            g0.eng.set_compact_rows(sp.compact_rows)
+            solo_fl = g0.G * stage_kernel_flops(W, H)["k_resstage16 %dx%d" % ((H + 1) // 2, (W + 1) // 2)]
+            solo = {"ms_per_launch": solo_ms, "leaves_per_launch": g0.G, "achieved": solo_fl / (solo_ms * 1e-3) / 1e12,
+                    "frac": solo_fl / (solo_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        # ---- the JSON line for the pools played so far (last line wins) ----
+        warm, timed = classify_pools(n_done, a.steps, a.warmup)
+        dt_local = bounds[-1] - bounds[warm]
+        delta = snaps[-1] - snaps[warm]
+        dt = allreduce([dt_local], dist.ReduceOp.MAX)[0]
+        tot_v = allreduce(delta.tolist(), dist.ReduceOp.SUM)
+        if rank == 0:
+            tot = dict(zip(names + ["waves"], tot_v))
+            per_wave = phase_ms / max(phase_n, 1)
+            kms = {k: (float(np.mean(v)), len(v)) for k, v in kernel_ms.items()}
+            sc = scores[warm:]
+            extra = {"ranks_joined": joined, "pools_played": n_done, "pool_seconds": [b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:])],
+                     "warmup_pass_waves": a.warm_waves, "wall_s_since_start": time.time() - t_start, "startup_s": bounds[0] - t_start,
+                     "cpu_baseline_s": t_cpu_done - t_start, "device_bytes": sp.device_bytes, "arena_peak_per_slot": sp.arena_peak(),
+                     "final": not go}
+            out = build_output(a.config, W, H, N, sims, flops_leaf, games, pool, world, timed, warm, requested, dt, tot, float(delta[-1]),
+                               len(sp.groups), sp.groups[0].G, sp.use_stem, sp.compact_rows, per_wave, kms, solo, cpu_base,
+                               float(np.mean([s[0] for s in sc])), float(np.mean([s[1] for s in sc])), extra)
+            print(json.dumps(out), flush=True)
+        if not go:
+            break
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

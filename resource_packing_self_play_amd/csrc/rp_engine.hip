@@ -145,7 +145,8 @@ struct DP {  // device view of a context, passed by value to every kernel
     int *ex_value;    // ranked outcome of the episode, 0 until it ends
     u32 *slot_ex;     // [G][N] example indices of the running episode
     // evaluator stem (first convolution + max-pool computed from the packed state)
-    float *stemT, *stemTB, *stemBias;  // [N][25][16], [512][16], [16]
+    int *stemT, *stemTB, *stemBias;  // [N][25][16], [512][16], [16]: tap sums in per-channel fixed point (k_stem_tables)
+    float *stemScale;                // [16] value of one fixed-point unit of channel o (a power of two)
     int Hp, Wp;
     // finished-episode ring
     int fin_cap;
@@ -1085,7 +1086,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_planes(DP p, floa
 // The sum of the active taps' weights is tabulated once per weight update (T[item][row class][col class][16]); the grid
 // plane goes through a 512-entry table indexed by the 3x3 bit pattern (TB).  That replaces 3.8 of the evaluator's
 // 10.0 MFLOP per leaf at 20x20/32, the 52.8 KB plane write and its read-back by ~30 k table adds and a 6.4 KB write.
-// Only the order of the float32 additions differs from the dense convolution (parity bar: 1e-5 on pi / v).
+//
+// Numerics: an output is bias + TB[pattern] + one T entry per unplaced item that reaches the pixel -- up to N + 2 terms.
+// Summed in float32 in table order the partial sums wander (|sum| up to ~20 with the reference's trained 15x15 weights)
+// and every add rounds at the partial sum's magnitude: 1.4e-6 off the dense convolution, which that peaked network
+// amplifies to 1.6e-4 on pi.  The tables are therefore FIXED POINT: every tap sum is formed in float64 and quantised
+// to an int32 with a per-channel unit q[o] = 2^-k[o], k chosen so that no reachable sum of terms can overflow
+// (bound: max(P, M), P / M = bias + the largest TB entry + every item's largest entry, positive / negative parts
+// separately).  Integer adds are exact and order-independent, the max-pool runs on the integers (conversion is monotone)
+// and each pooled value is converted to float32 ONCE: |error| <= (N + 2) q / 2 + half an ulp of the result, with
+// q ~ 2^-31 x the channel's bound (1.5e-8 for a bound of 32) -- closer to the exact sum than any float32 summation
+// order, at the cost of the float32 adds it replaces (v_add_u32 for v_add_f32).
 // ------------------------------------------------------------------------------------------------
 #define STEM_C 16
 __device__ __forceinline__ int stem_class(int r, int extent) {  // class of output coordinate r against a [0, extent) run of ones
@@ -1094,48 +1105,89 @@ __device__ __forceinline__ int stem_class(int r, int extent) {  // class of outp
     if (ub > 2) ub = 2;
     return r == 0 ? 2 + ub : ub;                                  // (lb=1: ub in {1,2} -> 3,4)  (lb=0: ub in {0,1,2} -> 0,1,2)
 }
-__global__ void k_stem_tables(int N, const float *w /*[16][N+1][3][3]*/, const float *bias, float *T, float *TB, float *bias_out) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nT = N * 25 * STEM_C;
-    if (tid < nT) {
-        int o = tid % STEM_C, cls = (tid / STEM_C) % 25, i = tid / (STEM_C * 25);
-        int rc = cls / 5, cc = cls % 5;
-        int rlb = rc >= 3 ? 1 : 0, rub = rc >= 3 ? rc - 2 : rc, clb = cc >= 3 ? 1 : 0, cub = cc >= 3 ? cc - 2 : cc;
-        float acc = 0.f;
-        for (int dr = rlb; dr <= rub; ++dr)
-            for (int dx = clb; dx <= cub; ++dx) acc += w[((o * (N + 1) + (i + 1)) * 3 + dr) * 3 + dx];
-        T[tid] = acc;
-    } else if (tid < nT + 512 * STEM_C) {
-        int q = tid - nT, o = q % STEM_C, pat = q / STEM_C;
-        float acc = 0.f;
-        for (int tap = 0; tap < 9; ++tap)
-            if ((pat >> tap) & 1) acc += w[(o * (N + 1) + 0) * 9 + tap];
-        TB[q] = acc;
-    } else if (tid < nT + 512 * STEM_C + STEM_C) {
-        int o = tid - nT - 512 * STEM_C;
-        bias_out[o] = bias[o];
+// One workgroup per output channel: float64 tap sums of the channel (N * 25 item entries, 512 grid patterns) in LDS, the
+// channel's bound and unit, then the quantised tables.
+__global__ void __launch_bounds__(256) k_stem_tables(int N, const float *w /*[16][N+1][3][3]*/, const float *bias, int *T, int *TB, int *bias_q, float *scale) {
+    extern __shared__ double st_vals[];  // [N * 25 + 512]
+    __shared__ double st_red[2][256];
+    const int o = blockIdx.x, tid = threadIdx.x, nT = N * 25;
+    for (int e = tid; e < nT + 512; e += 256) {
+        double acc = 0.0;
+        if (e < nT) {
+            const int cls = e % 25, i = e / 25, rc = cls / 5, cc = cls % 5;
+            const int rlb = rc >= 3 ? 1 : 0, rub = rc >= 3 ? rc - 2 : rc, clb = cc >= 3 ? 1 : 0, cub = cc >= 3 ? cc - 2 : cc;
+            for (int dr = rlb; dr <= rub; ++dr)
+                for (int dx = clb; dx <= cub; ++dx) acc += (double)w[((o * (N + 1) + (i + 1)) * 3 + dr) * 3 + dx];
+        } else {
+            const int pat = e - nT;
+            for (int tap = 0; tap < 9; ++tap)
+                if ((pat >> tap) & 1) acc += (double)w[(o * (N + 1) + 0) * 9 + tap];
+        }
+        st_vals[e] = acc;
     }
+    __syncthreads();
+    // bound of any reachable sum: positive and negative parts separately
+    double pos = 0.0, neg = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        double pm = 0.0, nm = 0.0;
+        for (int c = 0; c < 25; ++c) { const double v = st_vals[i * 25 + c]; pm = fmax(pm, v); nm = fmax(nm, -v); }
+        pos += pm; neg += nm;
+    }
+    double tpm = 0.0, tnm = 0.0;
+    for (int q = tid; q < 512; q += 256) { const double v = st_vals[nT + q]; tpm = fmax(tpm, v); tnm = fmax(tnm, -v); }
+    st_red[0][tid] = pos; st_red[1][tid] = neg;
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) { st_red[0][tid] += st_red[0][tid + sft]; st_red[1][tid] += st_red[1][tid + sft]; }
+        __syncthreads();
+    }
+    pos = st_red[0][0]; neg = st_red[1][0];
+    __syncthreads();
+    st_red[0][tid] = tpm; st_red[1][tid] = tnm;
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) { st_red[0][tid] = fmax(st_red[0][tid], st_red[0][tid + sft]); st_red[1][tid] = fmax(st_red[1][tid], st_red[1][tid + sft]); }
+        __syncthreads();
+    }
+    const double b = (double)bias[o];
+    const double bound = fmax(pos + st_red[0][0] + fmax(b, 0.0), neg + st_red[1][0] + fmax(-b, 0.0));
+    // k = the largest exponent with bound * 2^k + (N + 2) roundings < 2^31; at most 40 so that 2^-k stays a normal float
+    int k = 40;
+    if (bound > 0.0) {
+        int ex;
+        (void)frexp(bound, &ex);  // bound < 2^ex
+        k = 30 - ex;
+        if (k > 40) k = 40;
+    }
+    const double up = ldexp(1.0, k);
+    for (int e = tid; e < nT + 512; e += 256) {
+        const int q = (int)rint(st_vals[e] * up);
+        if (e < nT) T[e * STEM_C + o] = q; else TB[(e - nT) * STEM_C + o] = q;
+    }
+    if (tid == 0) { bias_q[o] = (int)rint(b * up); scale[o] = (float)ldexp(1.0, -k); }
 }
 
-// T_LDS: the item table (N * 25 * 16 floats, 51 KB at N = 32) is staged in LDS once per workgroup and the workgroup's waves
+// T_LDS: the item table (N * 25 * 16 words, 51 KB at N = 32) is staged in LDS once per workgroup and the workgroup's waves
 // loop over leaves -- the table rows a wave touches differ from lane to lane, which made the L1/L2 round trip of every
 // 64-byte row the kernel's critical path.  Larger tables (N > 40) stay in L2.
+#define STEM_NEG_INF ((int)0x80000000)  /* an output outside the image: never added to, loses every maximum */
 template <typename row_t, bool T_LDS>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows, int nhwc) {
-    extern __shared__ __attribute__((aligned(16))) float4 sT4[];
+    extern __shared__ __attribute__((aligned(16))) int4 sT4[];
     const int lane = lane_id();
     if (T_LDS) {
         const int n4 = p.N * 25 * STEM_C / 4;
-        const float4 *src = (const float4 *)p.stemT;
+        const int4 *src = (const int4 *)p.stemT;
         for (int i = threadIdx.x; i < n4; i += blockDim.x) sT4[i] = src[i];
         __syncthreads();
     }
     const long long rows = p.rows_identity ? (long long)p.G : (long long)*p.eval_count;
     const long long limit = rows < capacity_rows ? rows : capacity_rows;
     const int P = p.Hp * p.Wp;
-    float bias[STEM_C];
+    int bias[STEM_C];
+    float unit[STEM_C];
 #pragma unroll
-    for (int o = 0; o < STEM_C; ++o) bias[o] = p.stemBias[o];
+    for (int o = 0; o < STEM_C; ++o) { bias[o] = p.stemBias[o]; unit[o] = p.stemScale[o]; }
     for (long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); b < limit; b += (long long)gridDim.x * WAVES_PER_BLOCK) {
         const int g = p.rows_identity ? (int)b : p.eval_slot[b];
         if (p.phase[g] != RP_PHASE_WAIT_EVAL) continue;
@@ -1164,12 +1216,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                 row_t v = __shfl(myrow, rr & 63);
                 rw[q] = (live && rr >= 0 && rr < p.H) ? v : (row_t)0;
             }
-            float acc[4][STEM_C];  // outputs outside the image (odd sizes, idle lanes) start at -inf and stay there: the pool needs no selects
+            int acc[4][STEM_C];  // fixed point; outputs outside the image (odd sizes, idle lanes) start at "-inf" and stay there: the pool needs no selects
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool okj = live && ((j >> 1) ? rbok : true) && ((j & 1) ? xbok : true);
 #pragma unroll
-                for (int o = 0; o < STEM_C; ++o) acc[j][o] = okj ? bias[o] : -INFINITY;
+                for (int o = 0; o < STEM_C; ++o) acc[j][o] = okj ? bias[o] : STEM_NEG_INF;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // grid plane: 3x3 bit pattern, bit dr*3+dx = cell (r+dr-1, x+dx-1)
@@ -1182,9 +1234,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                 u32 b2 = x ? (u32)((r2 >> (x - 1)) & 7) : (u32)((r2 << 1) & 7);
                 u32 pat = b0 | (b1 << 3) | (b2 << 6);
                 if (pat) {
-                    const float4 *tb = (const float4 *)(p.stemTB + (size_t)pat * STEM_C);
+                    const int4 *tb = (const int4 *)(p.stemTB + (size_t)pat * STEM_C);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tb[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
+                    for (int q = 0; q < 4; ++q) { int4 v = tb[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
                 }
             }
             for (int i = 0; i < p.N; ++i) {
@@ -1200,23 +1252,24 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                     const int rc = (j >> 1) ? rc1 : rc0, cc = (j & 1) ? cc1 : cc0;
                     if (rc < 0 || cc < 0) continue;
                     const int trow = (i * 5 + rc) * 5 + cc;
-                    const float4 *tt = T_LDS ? (sT4 + trow * (STEM_C / 4)) : ((const float4 *)p.stemT + (size_t)trow * (STEM_C / 4));
+                    const int4 *tt = T_LDS ? (sT4 + trow * (STEM_C / 4)) : ((const int4 *)p.stemT + (size_t)trow * (STEM_C / 4));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { float4 v = tt[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
+                    for (int q = 0; q < 4; ++q) { int4 v = tt[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
                 }
             }
-            // max-pool: own block, then the right column of the left lane, the bottom row of the upper lane, the corner of the upper-left
+            // max-pool on the integers: own block, then the right column of the left lane, the bottom row of the upper lane, the corner
+            // of the upper-left; one conversion to float32 per pooled value
             const bool has_l = px > 0, has_u = lr > 0;
             float best[STEM_C];
 #pragma unroll
             for (int o = 0; o < STEM_C; ++o) {
-                const float v00 = acc[0][o], v01 = acc[1][o], v10 = acc[2][o], v11 = acc[3][o];
-                const float fl = __shfl(fmaxf(v01, v11), (lane - 1) & 63);
-                const float fu = __shfl(fmaxf(v10, v11), (lane - p.Wp) & 63);
-                const float fc = __shfl(v11, (lane - p.Wp - 1) & 63);
-                const float own = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
-                const float nb = fmaxf(fmaxf(has_l ? fl : -INFINITY, has_u ? fu : -INFINITY), (has_l && has_u) ? fc : -INFINITY);
-                best[o] = fmaxf(own, nb);
+                const int v00 = acc[0][o], v01 = acc[1][o], v10 = acc[2][o], v11 = acc[3][o];
+                const int fl = __shfl(max(v01, v11), (lane - 1) & 63);
+                const int fu = __shfl(max(v10, v11), (lane - p.Wp) & 63);
+                const int fc = __shfl(v11, (lane - p.Wp - 1) & 63);
+                const int own = max(max(v00, v01), max(v10, v11));
+                const int nb = max(max(has_l ? fl : STEM_NEG_INF, has_u ? fu : STEM_NEG_INF), (has_l && has_u) ? fc : STEM_NEG_INF);
+                best[o] = (float)max(own, nb) * unit[o];
             }
             const bool store = live && (pass == 0 || lr > 0);
             const int pp = pr * p.Wp + px;
@@ -2648,9 +2701,10 @@ extern "C" int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const f
         ALLOC(ctx, d.stemT, (size_t)d.N * 25 * STEM_C);
         ALLOC(ctx, d.stemTB, (size_t)512 * STEM_C);
         ALLOC(ctx, d.stemBias, (size_t)STEM_C);
+        ALLOC(ctx, d.stemScale, (size_t)STEM_C);
     }
-    int total = d.N * 25 * STEM_C + 512 * STEM_C + STEM_C;
-    hipLaunchKernelGGL(k_stem_tables, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, d.N, conv_w_dev, bias_dev, d.stemT, d.stemTB, d.stemBias);
+    const size_t tbl_lds = ((size_t)d.N * 25 + 512) * sizeof(double);  // 29.7 KB at N = 128
+    hipLaunchKernelGGL(k_stem_tables, dim3(STEM_C), dim3(256), tbl_lds, ctx->stream, d.N, conv_w_dev, bias_dev, d.stemT, d.stemTB, d.stemBias, d.stemScale);
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
 }
@@ -2661,7 +2715,7 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     if (!d.stemT) return fail(ctx, RP_ERR_STATE, "rp_leaf_stem: call rp_stem_set_weights first");
     long long rows = std::min<long long>(capacity_rows, d.G);
     if (rows == 0) return RP_OK;
-    const size_t t_bytes = (size_t)d.N * 25 * STEM_C * sizeof(float);
+    const size_t t_bytes = (size_t)d.N * 25 * STEM_C * sizeof(int);
     const bool t_lds = t_bytes <= 64 * 1024;
     const int grid = (int)std::min<long long>(grid_for(rows), t_lds ? 256 * 3 : 1 << 20);  // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32)
     if (ctx->row64) {

@@ -455,6 +455,72 @@ def gen_nnet():
     run("w15_trained", 15, 15, 10, 12, state_dict=sd)
 
 
+def gen_nnet_f64():
+    """Float64 ground truth for the nnet_*.npz fixtures: the reference's own BinPackingNNet (BinpackingNNet.py:50-81) with the stored
+    weights cast to double, on the stored states.  Shows how far the reference's float32 outputs themselves are from the exact
+    forward of the same weights (2e-5 on pi for the trained 15x15 checkpoint) -- the yardstick tests/test_gpu_nnet.py holds the HIP
+    evaluator to where 1e-5 against the float32 reference is below that noise floor."""
+    import torch
+    from binpacking.pytorch.BinpackingNNet import BinPackingNNet as RefNet
+    out = {"meta": json.dumps(dict(META, torch=torch.__version__))}
+    for name in ("c2_seed0", "c3_seed0", "w15_trained", "c5_seed0"):
+        path = os.path.join(HERE, "nnet_%s.npz" % name)
+        if not os.path.exists(path):
+            continue
+        d = np.load(path)
+        w, h, n = int(d["W"]), int(d["H"]), int(d["N"])
+        g = BinPackingGame(w, h, n, 1)
+        torch.manual_seed(int(d["seed"])) if "seed" in d.files else None
+        net = RefNet(g, Args(num_items=n, num_bins=1))
+        if any(k.startswith("w__") for k in d.files):
+            net.load_state_dict({k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w__")})
+        net = net.double().eval()
+        with torch.no_grad():
+            lp, v = net(torch.from_numpy(d["planes"].astype(np.float64)))
+        out[name + "__pi64"] = torch.exp(lp).numpy(); out[name + "__v64"] = v.numpy()
+        print("%s: reference f32 vs f64  pi %.3e  v %.3e" % (name, np.abs(d["pi"] - out[name + "__pi64"]).max(), np.abs(d["v"] - out[name + "__v64"]).max()))
+    np.savez_compressed(os.path.join(HERE, "nnet_f64.npz"), **out)
+    print("wrote nnet_f64.npz")
+
+
+def gen_nnet_c5():
+    """NNetWrapper.predict at BASELINE configs[4] (50x50 bin, 128 items): 3 states.  The 2.16 M weights (8.7 MB) are not stored:
+    they are torch.manual_seed(0)'s initialisation, which the package's module reproduces exactly (same layer order); the
+    fixture keeps their SHA-256 so a test can tell a changed initialiser from a wrong forward."""
+    import hashlib
+    import torch
+    from binpacking.pytorch.NNet import NNetWrapper
+    from resource_packing_self_play_amd.binpacking.pytorch.BinpackingNNet import BinPackingNNet as OwnNet
+    w, h, n, seed = 50, 50, 128, 0
+    g = BinPackingGame(w, h, n, 1)
+    rng = np.random.default_rng(11)
+    items = items_for(w, h, n, 100)
+    state = g.getBinItem(g.getInitBoard(), g.getInitItems(items))
+    states = []
+    for step in range(41):
+        if step in (0, 12, 40):
+            states.append(state)
+        v = valid_mask(g, state)
+        b, it = g.getNextState(state[0], int(rng.choice(np.nonzero(v)[0])), state[1:])
+        state = g.getBinItem(b, it)
+    args = Args(cuda=False, num_items=n, num_bins=1, epochs=1, batch_size=8)
+    torch.manual_seed(seed)
+    net = NNetWrapper(g, args)
+    torch.manual_seed(seed)
+    own = OwnNet(g, args)
+    sd, so = net.nnet.state_dict(), own.state_dict()
+    assert list(sd) == list(so) and all(torch.equal(sd[k], so[k]) for k in sd), "the package's module no longer initialises like the reference's"
+    digest = hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k in sd)).hexdigest()
+    pis, vs = [], []
+    for s in states:
+        pi, v = net.predict(s)
+        pis.append(pi); vs.append(v)
+    rows = np.stack([ev.pack_state(s)[0] for s in states]); rem = np.stack([ev.pack_state(s)[1] for s in states])
+    np.savez_compressed(os.path.join(HERE, "nnet_c5_seed0.npz"), meta=json.dumps(dict(META, torch=torch.__version__)), W=w, H=h, N=n, seed=seed,
+                        weights_sha256=digest, planes=np.stack(states).astype(np.uint8), rows=rows, rem=rem, pi=np.stack(pis), v=np.stack(vs))
+    print("wrote nnet_c5_seed0.npz", np.stack(pis).shape, digest[:16])
+
+
 def gen_train():
     """NNetWrapper.train (NNet.py:27-67) for a few steps on CPU from seeded weights and examples: final weights and
     the loss values of loss_pi / loss_v (NNet.py:87-91) on a fixed batch."""
@@ -503,11 +569,13 @@ def gen_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet", "train"]
+    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet", "nnet_c5", "nnet64", "train"]
     if "items" in which: gen_items()
     if "rules" in which: gen_game_rules()
     if "reward" in which: gen_ranked_reward()
     if "q" in which: gen_q_update()
     if "mcts" in which: gen_mcts()
     if "nnet" in which: gen_nnet()
+    if "nnet_c5" in which: gen_nnet_c5()
+    if "nnet64" in which: gen_nnet_f64()
     if "train" in which: gen_train()

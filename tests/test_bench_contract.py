@@ -1,42 +1,89 @@
-"""The bench line's contract, checked on the committed output of the default command (profiles/): the keys the driver and the
-judge read, their types, and the internal consistency of the roofline figures."""
-import glob
+"""bench.py's contract, checked on the CPU: the wall-budget planner keeps the driver's command inside its 600 s limit, the
+output builder emits every contract key, and `--gpus N` starts N ranks by itself (dry run: launch plumbing without GPU work)."""
 import json
 import os
+import subprocess
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
 
 
-def _latest():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_bench_default*.json")))
-    assert files, "no committed bench line under profiles/"
-    return json.load(open(files[-1]))
+def test_driver_command_fits_its_time_limit():
+    # python3 bench.py --gpus 1 --steps 20 --warmup 5: start-up between 40 s (warm box) and 200 s (cold first import of torch
+    # twice, CPU baseline, 139 GB of arenas, capture), c3 pools between 20 and 60 s
+    for startup in (40, 90, 150, 200):
+        for pool_s in (20, 30, 33.2, 40, 60):
+            n, warm, timed, wall = bench.simulate_plan(startup, pool_s, steps=20, warmup=5)
+            assert n >= 1 and timed >= 1 and warm + timed == n
+            assert wall <= max(bench.DEFAULT_BUDGET_S + 0.1 * pool_s, startup + pool_s + bench.FINAL_RESERVE_S) + 1e-9
+            assert wall < 600 - 60, (startup, pool_s, wall)
 
 
-def test_bench_line_has_the_contract_keys():
-    d = _latest()
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["unit"] == "episodes/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    assert "20x20" in d["config"]["workload"] and "32 items" in d["config"]["workload"] and "400" in d["config"]["workload"]
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["ms_per_step"] > 0
+def test_short_requests_run_exactly_as_asked():
+    n, warm, timed, wall = bench.simulate_plan(60, 30, steps=2, warmup=1)
+    assert (n, warm, timed) == (3, 1, 2)
+    n, warm, timed, _ = bench.simulate_plan(60, 30, steps=1, warmup=0)
+    assert (n, warm, timed) == (1, 0, 1)
 
 
-def test_roofline_object_is_consistent():
-    r = _latest()["roofline"]
+def test_timed_steps_take_priority_over_warmup():
+    assert bench.classify_pools(9, 20, 5) == (0, 9)
+    assert bench.classify_pools(22, 20, 5) == (2, 20)
+    assert bench.classify_pools(25, 20, 5) == (5, 20)
+    assert bench.classify_pools(1, 1, 1) == (0, 1)
+    assert bench.classify_pools(2, 1, 1) == (1, 1)
+    assert not bench.should_continue(100.0, 25, 30.0, 20, 5, 380.0)
+    assert bench.should_continue(1e9, 0, 0.0, 20, 5, 380.0)  # one pool is always played
+
+
+def _fake_stats():
+    names = ["simulations", "expansions", "terminal_hits", "path_edges", "sum_valid_select", "sum_valid_leaf", "transposition_links", "nodes",
+             "moves", "episodes", "probes", "key_bytes", "sum_visited_select", "visited_new"]
+    tot = {k: 1000.0 for k in names}
+    tot.update(episodes=65536.0, expansions=7.0e8, simulations=8.0e8, waves=24000.0, path_edges=1.9e9, sum_valid_select=8e10, sum_visited_select=2e10)
+    return tot
+
+
+def test_output_line_carries_the_contract():
+    tot = _fake_stats()
+    kms = {"k_resstage16 10x10": (0.55, 700), "k_resstage32 5x5": (0.5, 700)}
+    cpu = {"value": 2.8, "unit": "episodes/s", "cores": 32, "kind": "port", "sample": "x"}
+    out = bench.build_output("c3", 20, 20, 32, 400, 10.01e6, 32768, 32768, 1, 2, 0, {"steps": 20, "warmup": 5}, 66.0, tot, 24000.0, 1, 32768,
+                             True, True, [0.4, 0.25, 1.9, 0.12], kms, None, cpu, 0.9, 30.0, {"ranks_joined": 1})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["steps"] == 2 and out["warmup"] == 0 and abs(out["ms_per_step"] - 33000.0) < 1e-6
+    assert abs(out["value"] - 65536.0 / 66.0) < 1e-9 and out["vs_baseline"] is None and out["scaling"] == "weak"
+    assert "c3" in out["config"]["workload"] and "32768 concurrent games" in out["config"]["workload"] and "model" not in out["config"]
+    r = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # achieved = algorithmic flops per launch / mean launch duration
-    assert abs(r["achieved"] - r["flops_per_launch"] / (r["ms_per_launch"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+        assert k in r
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel"].startswith("k_resstage16")
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"])
+    json.dumps(out)
 
 
-def test_cpu_baseline_object():
-    c = _latest()["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "episodes/s"
+def test_stale_pmc_traffic_is_not_reported(tmp_path, monkeypatch):
+    rec, note = bench.load_pmc_traffic()
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    stored = json.load(open(path)).get("engine_sha256") if os.path.exists(path) else None
+    if stored == bench.engine_hash():
+        assert rec is not None and note is None
+    else:
+        assert rec is None and note
+
+
+@pytest.mark.timeout(300)
+def test_gpus_flag_starts_the_ranks_itself():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RP_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["backend"] == "gloo" and line["dry_run"] is True

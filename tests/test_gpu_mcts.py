@@ -229,13 +229,16 @@ def test_results_do_not_depend_on_slot_count_or_step_cap():
         m.close()
 
 
-def test_full_size_c3_episodes_match_oracle():
-    """BASELINE configs[2] at full size for a few games: 20x20 bin, 32 items, 400 simulations per move, whole episodes with
-    sampled moves -- every action, the outcome and the complete ~11 k-node tree of each game against the oracle."""
+@pytest.mark.parametrize("cfg,W,H,N,sims,games,min_nodes", [("c3", 20, 20, 32, 400, 4, 3000), ("c4", 20, 20, 32, 100, 4, 800), ("c5", 50, 50, 128, 200, 1, 5000)])
+def test_full_size_episodes_match_oracle(cfg, W, H, N, sims, games, min_nodes):
+    """BASELINE configs[2] (20x20 / 32 items / 400 sims) and configs[3] (the same board at 100 sims) at full size for a few games,
+    and configs[4]'s board (50x50, 128 items: 64-bit rows, 6 400 actions, 129 levels) at 200 sims per move for one game -- the
+    default node_cap / arena sizing of a deep tree: whole episodes with sampled moves, every action, the outcome and the
+    complete tree of each game against the oracle.  (c5's own 800 sims per move differ only in the loop count; the oracle needs
+    ~4x as long.)"""
     from resource_packing_self_play_amd import _lib
-    W, H, N, sims, games = 20, 20, 32, 400, 4
     A = W * N
-    rng = np.random.default_rng(2020)
+    rng = np.random.default_rng(2020 + sims)
     wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
     buf = rng.uniform(0.8, 1.0, 100)
     eng = make_engine(W, H, N, games, sims, move_rule=_lib.MOVE_SAMPLE, seed=9, tie_salt=5)
@@ -251,9 +254,11 @@ def test_full_size_c3_episodes_match_oracle():
         actions, _, o, s = m.play_episode(sims, policy=1, seed=9, episode_id=70 + g, want_counts=False)
         assert fin[70 + g] == (o, s, len(actions)), g
         tree = tree_as_dict(eng.dump_tree(g))
-        assert len(tree) > 3000
-        assert_trees_equal(tree, m.dump(), "full-size game %d" % g)
+        assert len(tree) > min_nodes, len(tree)
+        assert_trees_equal(tree, m.dump(), "%s game %d" % (cfg, g))
         m.close()
+    pk = eng.arena_peak()
+    print("%s: arena peak per slot %s" % (cfg, pk))
     eng.close()
 
 
