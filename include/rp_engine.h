@@ -174,7 +174,10 @@ int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows);
  * leaf states, exploiting that item planes are origin-anchored rectangles (tabulated tap sums).  rp_stem_set_weights reads
  * the DEVICE weight [16][N+1][3][3] and bias [16] tensors and rebuilds the tables (call again after every weight update);
  * rp_leaf_stem writes FP32 [n][16][(H+1)/2][(W+1)/2] into caller-owned DEVICE memory, the input of conv_seqs[0].res_block0.
- * Same result as rp_leaf_planes + the two PyTorch ops up to float32 summation order. */
+ * The tap sums are tabulated in per-channel fixed point (float64 sums quantised to int32, unit 2^-k chosen from the channel's
+ * bound), added as integers and converted to float32 once: within (N + 2) half units + half an ulp of the exact sum, i.e. the
+ * correctly rounded convolution for practical purposes; rp_leaf_planes + the two PyTorch ops differ from it by their own
+ * float32 summation error. */
 int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const float *bias_dev);
 int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), may be NULL */, int64_t capacity_rows,
                  int32_t channels_last /* 0: [n][16][Hp][Wp], 1: [n][Hp][Wp][16] (MIOpen's FP32 kernels are faster on NHWC) */);
@@ -253,6 +256,10 @@ int rp_examples_count(rp_ctx *ctx, int64_t *n_out);
  * pi FP32 [count][W*N] (= counts / sum, MCTS_bpp.py:51-54), value FP32 [count] (the episode's ranked
  * outcome, 0 while the episode is unfinished) -- DEVICE buffers. */
 int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes_dev, float *pi_dev, float *value_dev);
+/* Episode id and move number (0-based) of examples [first, first+count) -- HOST buffers.  The buffer fills in completion
+ * order across slots; the reference appends episode by episode, move by move (CoachBPP.py:80,133), so callers sort by
+ * (episode, move) before they trim to maxlenOfQueue (CoachBPP.py:122). */
+int rp_examples_meta(rp_ctx *ctx, int64_t first, int64_t count, uint64_t *episode_id_out, int32_t *move_out);
 int rp_examples_clear(rp_ctx *ctx);
 
 /* ---- inspection (parity tests) --------------------------------------------------------- */

@@ -11,7 +11,9 @@ entropy:
     each sequential episode, CoachBPP.py:134);
   * moves are sampled with the engine's counter-based RNG instead of `np.random.seed(); np.random.choice`
     (CoachBPP.py:86-87), greedy ties go to the lowest action instead of a random one (MCTS_bpp.py:45-46);
-  * the per-episode generator seeds are drawn up front from one OS-seeded stream.
+  * the per-episode generator seeds are drawn up front from one OS-seeded stream (`drawIteration`);
+  * with several ranks a training step still covers `batch_size` examples: one index stream shared by all ranks, each rank
+    takes every world-th index, gradients are summed (see `NNetWrapper.train_tensors`).
 `executeEpisode` keeps the reference's sequential semantics through the `MCTS` / `BinPackingGame` classes.
 """
 import logging
@@ -41,6 +43,7 @@ class CoachBPP:
         self.skipFirstSelfPlay = False
         self.gen = gen
         self.metrics_log = []  # dicts with the reference's W&B metric names, one per iteration
+        self.iteration_scores = []  # ep_scores of every iteration, in episode order
         self._selfplay = None
 
     # ---- sequential episode, reference semantics (CoachBPP.py:50-99) --------------------------------------------------
@@ -62,66 +65,89 @@ class CoachBPP:
                 return [(x[0], x[1], r) for x in trainExamples]
 
     # ---- batched iteration ------------------------------------------------------------------------------------------
-    def _driver(self):
+    def _driver(self, n_eps):
         if self._selfplay is None:
             from .selfplay import BatchedSelfPlay
             world = rdist.world_size()
-            per_rank = (int(self.args.numEps) + world - 1) // world
+            per_rank = (int(n_eps) + world - 1) // world
             games = int(getattr(self.args, "games_per_gpu", 0) or per_rank)
             moves_cap = self.game.num_items
             self._selfplay = BatchedSelfPlay(self.game, self.nnet, self.args, games=min(games, per_rank), move_rule=_lib.MOVE_SAMPLE,
-                                             seed=int(getattr(self.args, "seed", 0) or 0) * 1000003 + rdist.rank(),
+                                             seed=int(getattr(self.args, "seed", 0) or 0) * 1000003 + 17,  # the same on every rank
                                              node_cap=int(getattr(self.args, "node_cap", 0) or 0),
                                              edge_cap=int(getattr(self.args, "edge_cap", 0) or 0),
                                              max_examples=2 * per_rank * moves_cap, use_graph=bool(getattr(self.args, "use_graph", True)),
-                                             groups=int(getattr(self.args, "groups", 2) or 2))
+                                             groups=int(getattr(self.args, "groups", 2) or 2),
+                                             tie_salt=getattr(self.args, "tie_salt", None), host_evaluator=getattr(self.args, "host_evaluator", None))
         return self._selfplay
 
-    def selfPlayIteration(self, i):
-        """Self-play of iteration i: returns (ep_scores in episode order, (planes, pi, value) of all ranks)."""
+    def drawIteration(self):
+        """(generator height, [generator seed per episode]) of one iteration (CoachBPP.py:117-118,127), identical on every rank.
+        The reference draws them from an OS-seeded stream one episode at a time; here they are drawn up front."""
         import torch
         args = self.args
         np.random.seed()  # CoachBPP.py:117
-        if rdist.world_size() > 1:  # every rank must draw the same instances
-            draw = torch.tensor([np.random.randint(args.binH_min, args.binH + 1)] + [np.random.randint(int(1e5)) for _ in range(args.numEps)],
-                                dtype=torch.int64, device=self.nnet.device)
-            torch.distributed.broadcast(draw, src=0)
-            draw = draw.cpu().tolist()
-        else:
-            draw = [np.random.randint(args.binH_min, args.binH + 1)] + [np.random.randint(int(1e5)) for _ in range(args.numEps)]
-        self.gen.bin_height = int(draw[0])  # :118
+        draw = [np.random.randint(args.binH_min, args.binH + 1)] + [np.random.randint(int(1e5)) for _ in range(args.numEps)]
+        if rdist.world_size() > 1:  # every rank must play the same instances
+            t = torch.tensor(draw, dtype=torch.int64, device=self.nnet.device)
+            torch.distributed.broadcast(t, src=0)
+            draw = t.cpu().tolist()
+        return int(draw[0]), [int(x) for x in draw[1:]]
+
+    def selfPlayIteration(self, i, draws=None, move_rule=None):
+        """Self-play of iteration i: returns (ep_scores in episode order, (planes, pi, value) of all ranks in the reference's order:
+        episode by episode, move by move).  draws: (generator height, seeds) instead of drawIteration()'s (tests pin the
+        reference's captured draws); move_rule: overrides sampling / greedy (tests: argmax moves with proportional targets)."""
+        import torch
+        args = self.args
+        bin_height, seeds = self.drawIteration() if draws is None else (int(draws[0]), [int(x) for x in draws[1]])
+        n_eps = len(seeds)
+        self.gen.bin_height = bin_height  # :118
         self.items_total_area = self.gen.bin_height * self.gen.bin_width  # :119
-        seeds = draw[1:]
+        state = np.random.get_state()  # items_generator reseeds the global stream (BinPackingGame.py:258)
         wh = np.array([[it[:2] for it in self.gen.items_generator(s)] for s in seeds], dtype=np.uint8)  # :127-130
-        mine = rdist.shard(args.numEps)
-        sp = self._driver()
+        np.random.set_state(state)
+        mine = rdist.shard(n_eps)
+        sp = self._driver(n_eps)
         greedy = i > args.iterStepThreshold  # :132
-        if getattr(self, "_greedy_mode", None) != greedy:
-            sp.set_move_rule(_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, onehot_examples=greedy)  # re-captures the waves
-            self._greedy_mode = greedy
+        mode = (_lib.MOVE_ARGMAX_FIRST if greedy else _lib.MOVE_SAMPLE, bool(greedy)) if move_rule is None else (int(move_rule), bool(greedy))
+        if getattr(self, "_move_mode", None) != mode:
+            sp.set_move_rule(mode[0], onehot_examples=mode[1])  # re-captures the waves
+            self._move_mode = mode
         sp.clear_examples()
+        first = mine[0] if mine else 0  # episode ids are global: first .. first + len(mine) - 1
         ids, outcome, score, moves, stats = sp.run(wh[mine], np.full(len(mine), self.items_total_area, np.int32), self.rewards_list,
-                                                   first_id=0)
-        local = torch.zeros(len(mine), dtype=torch.float64, device=self.nnet.device)
-        local[torch.as_tensor(ids.astype(np.int64), device=self.nnet.device)] = torch.as_tensor(score, device=self.nnet.device)
+                                                   first_id=first)
+        dev = self.nnet.device
+        mine_t = torch.as_tensor(mine, dtype=torch.int64, device=dev)
+        local = torch.zeros(len(mine), dtype=torch.float64, device=dev)
+        local[torch.as_tensor(ids.astype(np.int64) - first, device=dev)] = torch.as_tensor(score, device=dev)
+        planes, pi, value, ex_ep, ex_mv = sp.examples(with_meta=True)
+        key = torch.as_tensor(ex_ep.astype(np.int64) * (self.game.num_items + 1) + ex_mv.astype(np.int64), device=dev)
         if rdist.world_size() > 1:
-            gathered = rdist.all_gather_variable(torch.stack([torch.as_tensor(mine, dtype=torch.float64, device=self.nnet.device), local], dim=1))
-            ep_scores = np.zeros(args.numEps)
+            gathered = rdist.all_gather_variable(torch.stack([mine_t.to(torch.float64), local], dim=1))
+            ep_scores = np.zeros(n_eps)
             g = gathered.cpu().numpy()
             ep_scores[g[:, 0].astype(np.int64)] = g[:, 1]
+            planes, pi, value = rdist.all_gather_examples(planes, pi, value)
+            order = torch.argsort(rdist.all_gather_variable(key))  # rank order -> (episode, move) order, the same on every rank
+            planes, pi, value = planes.index_select(0, order), pi.index_select(0, order), value.index_select(0, order)
         else:
             ep_scores = local.cpu().numpy()
-        examples = rdist.all_gather_examples(*sp.examples())
         self.last_stats = stats
-        return [float(s) for s in ep_scores], examples
+        self.last_example_keys = key  # episode * (N + 1) + move of every LOCAL example (tests)
+        return [float(s) for s in ep_scores], (planes, pi, value)
 
     def learn(self):
         import torch
         args = self.args
+        if rdist.world_size() > 1 and getattr(self.nnet, "grad_hook", None) is None:
+            rdist.attach(self.nnet)  # identical weights on every rank, gradients summed over the ranks' batch slices
         for i in range(1, args.numIters + 1):
             log.info("Starting Iter #%d ...", i)
             if not self.skipFirstSelfPlay or i > 1:
                 ep_scores, examples = self.selfPlayIteration(i)
+                self.iteration_scores.append(list(ep_scores))
                 self.rewards_list.extend(ep_scores)  # :134, in episode order
                 while len(self.rewards_list) > args.numScoresForRank:  # :136-139 drop the smallest score
                     self.rewards_list.pop(int(np.argmin(self.rewards_list)))
@@ -131,7 +157,7 @@ class CoachBPP:
                            "min reward": float(np.min(ep_scores)), "max reward": float(np.max(ep_scores))}  # :143-147
                 self.metrics_log.append(dict(metrics, iteration=i))
                 log.info("iter %d: %s", i, metrics)
-                keep = int(args.maxlenOfQueue)  # deque(maxlen=maxlenOfQueue) (:122)
+                keep = int(args.maxlenOfQueue)  # deque(maxlen=maxlenOfQueue) (:122): the LAST maxlen examples in episode order
                 self.trainExamplesHistory.append(tuple(t[-keep:] for t in examples))
             if len(self.trainExamplesHistory) > args.numItersForTrainExamplesHistory:  # :154-157
                 log.warning("Removing the oldest entry in trainExamples. len(trainExamplesHistory) = %d", len(self.trainExamplesHistory))

@@ -84,6 +84,7 @@ _SIGS = {
     "rp_counters": (C.c_int, [_vp, _vp, _i32]),
     "rp_examples_count": (C.c_int, [_vp, _vp]),
     "rp_examples_tensors": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "rp_examples_meta": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "rp_examples_clear": (C.c_int, [_vp]),
     "rp_tree_size": (C.c_int, [_vp, _i32, _vp, _vp]),
     "rp_arena_peak": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -87,25 +87,41 @@ class NNetWrapper(NeuralNet):
     def train_tensors(self, planes, target_pi, target_v):
         """Same schedule as the reference: a fresh Adam with default hyper-parameters (`args.lr` is never read there,
         reference :31), `epochs` x floor(len / batch_size) steps, each on `batch_size` examples drawn WITH replacement
-        from NumPy's global stream (:39-43), loss = -sum(pi * log p)/B + sum((v - v_hat)^2)/B (:87-91)."""
+        from NumPy's global stream (:39-43), loss = -sum(pi * log p)/B + sum((v - v_hat)^2)/B (:87-91).
+
+        Data parallel (grad_hook set by distributed.attach): the step is STILL one batch of `batch_size` examples.  Rank 0 draws
+        one seed from its global stream, every rank derives the same index stream from it and takes every world-th index of
+        each batch; its loss terms are divided by the full batch size and the hook SUMS the gradients, so the update equals the
+        single-process one on the same indices (up to float32 summation order) at the reference's learning rate."""
         n = planes.shape[0]
         optimizer = optim.Adam(self.nnet.parameters())
         history = []
+        world, rank = 1, 0
+        draw = np.random.randint
+        if self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        if world > 1:
+            seed = torch.tensor([np.random.randint(1 << 31) if rank == 0 else 0], dtype=torch.int64, device=planes.device)
+            torch.distributed.broadcast(seed, src=0)
+            draw = np.random.RandomState(int(seed.item())).randint
+        B = int(self.args.batch_size)
         for epoch in range(self.args.epochs):
             self.nnet.train()
             pi_losses, v_losses = AverageMeter(), AverageMeter()
-            for _ in range(int(n / self.args.batch_size)):
-                ids = torch.as_tensor(np.random.randint(n, size=self.args.batch_size), device=planes.device)
+            for _ in range(int(n / B)):
+                ids_all = draw(n, size=B)
+                ids = torch.as_tensor(ids_all[rank::world], device=planes.device)
                 out_pi, out_v = self.nnet(planes.index_select(0, ids))
-                l_pi = self.loss_pi(target_pi.index_select(0, ids), out_pi)
-                l_v = self.loss_v(target_v.index_select(0, ids), out_v)
+                # loss_pi / loss_v (:87-91) with the FULL batch size as the divisor: a rank's slice contributes its share
+                l_pi = -torch.sum(target_pi.index_select(0, ids) * out_pi) / B
+                l_v = torch.sum((target_v.index_select(0, ids) - out_v.view(-1)) ** 2) / B
                 optimizer.zero_grad()
                 (l_pi + l_v).backward()
                 if self.grad_hook is not None:
-                    self.grad_hook(self.nnet)
+                    l_pi, l_v = self.grad_hook(self.nnet, (l_pi.detach(), l_v.detach()))
                 optimizer.step()
-                pi_losses.update(l_pi.item(), self.args.batch_size)
-                v_losses.update(l_v.item(), self.args.batch_size)
+                pi_losses.update(float(l_pi), B)
+                v_losses.update(float(l_v), B)
             history.append((pi_losses.avg, v_losses.avg))
             if self.log:
                 print("EPOCH ::: %d  Loss_pi=%s Loss_v=%s" % (epoch + 1, pi_losses, v_losses))

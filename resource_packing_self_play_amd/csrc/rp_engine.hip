@@ -143,6 +143,8 @@ struct DP {  // device view of a context, passed by value to every kernel
     u8 *ex_wh;        // [max_examples][N][2]
     u32 *ex_counts;   // [max_examples][A]  root visit counts
     int *ex_value;    // ranked outcome of the episode, 0 until it ends
+    u64 *ex_episode;  // episode id and move number of every example: the buffer fills in completion order across slots,
+    int *ex_move;     // the reference appends episode by episode, move by move (CoachBPP.py:80,133)
     u32 *slot_ex;     // [G][N] example indices of the running episode
     // evaluator stem (first convolution + max-pool computed from the packed state)
     int *stemT, *stemTB, *stemBias;  // [N][25][16], [512][16], [16]: tap sums in per-channel fixed point (k_stem_tables)
@@ -409,8 +411,9 @@ template <typename row_t> struct Tree {
     Arena pa, va;  // legal-move runs, visited blocks
     u32 n_nodes;
     u64 c_probes, c_keybytes, c_nodes;
+    u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
 
-    __device__ Tree(const DP &p_, int g_) : p(p_), g(g_) {
+    __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr) : p(p_), g(g_), stage(stage_) {
         hdr = p.hdr + (size_t)g * p.node_cap;
         key = p.key + (size_t)g * p.node_cap * p.KW;
         size_t eb = (size_t)g * p.edge_cap, vb = (size_t)g * p.vis_cap;
@@ -505,21 +508,23 @@ template <typename row_t> struct Tree {
         const u32 id = n_nodes;
         store_key(id, myrow, rem0, rem1);
         const int level = level_of(p.N, rem0, rem1);
-        u32 need = (u32)(p.N - level) * (u32)p.W, room;  // at most one legal move per (unplaced item, column)
-        if (need > (u32)p.A) need = (u32)p.A;
-        const u32 off = arena_reserve(pa, level, need, &room);
-        if (off == NONE32) {
-            if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
-            return NONE32;
-        }
+        // The legal moves go to the wave's LDS staging run first, so the arena is asked for exactly as many entries as the node
+        // has (a run reserved for the worst case -- one move per unplaced item and column -- opened a fresh chunk per node on
+        // large boards: 460 of 6 400 entries used at 50x50/128).
         ValidSink sink;
-        sink.act = pAct + off; sink.mask = nullptr; sink.cap = (int)room;
-        int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
-        if (nv < 0) {
-            if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
-            return NONE32;
+        sink.act = stage; sink.mask = nullptr; sink.cap = p.A;
+        const int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
+        wave_sync();
+        u32 room, off = 0;
+        if (nv > 0) {
+            off = arena_reserve(pa, level, (u32)nv, &room);
+            if (off == NONE32) {
+                if (lane_id() == 0) set_error(p, ERR_EDGE_CAP);
+                return NONE32;
+            }
+            for (int k = lane_id(); k < nv; k += 64) pAct[off + k] = stage[k];
+            arena_commit(pa, level, (u32)nv);
         }
-        arena_commit(pa, level, (u32)nv);
         NodeHdr hd;
         hd.ns = 0; hd.prior_off = off; hd.vis_off = 0; hd.n_valid = (u16)nv; hd.vis_n = 0; hd.vis_cap = 0; hd.term = 0;
         hd.flags = (u8)(RP_KIND_WEAK << 2); hd.depth = (u8)level; hd.pad[0] = hd.pad[1] = hd.pad[2] = 0; hd.norm = 0.0;
@@ -758,7 +763,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
                 for (u32 q = lane; q < hd.vis_n; q += 64)  // hd may have grown by one entry above: re-read the header's view
                     ec[t.pAct[hd.prior_off + t.vIdx[hd.vis_off + q]]] = t.vN[hd.vis_off + q] & NSA_MASK;
             }
-            if (lane == 0) { p.ex_value[idx] = 0; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
+            if (lane == 0) { p.ex_value[idx] = 0; p.ex_episode[idx] = p.episode[g]; p.ex_move[idx] = mv; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
         } else if (lane == 0) {
             set_error(p, ERR_EXAMPLES_CAP);
         }
@@ -847,12 +852,13 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(DP p) {
     __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    extern __shared__ u16 s_stage[];  // [WAVES_PER_BLOCK][A]
     u32 *vmask = s_vmask[threadIdx.x >> 6];
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (g >= p.G) return;
     int phase = p.phase[g];
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
-    Tree<row_t> t(p, g);
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
     u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
@@ -935,7 +941,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= p.G) return;
     if (p.phase[g] != RP_PHASE_MOVE_READY) return;
-    Tree<row_t> t(p, g);
+    extern __shared__ u16 s_stage[];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
     u32 c[CNT_N];
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
@@ -1335,7 +1342,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
         }
         wave_sync();
     }
-    Tree<row_t> t(p, g);
+    extern __shared__ u16 s_stage[];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
     if (clear_tree) { t.reset_arenas(); wave_sync(); }
     row_t myrow; u64 rem0, rem1;
     if (rows) {
@@ -1364,7 +1372,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     const int g = first + k;
     int phase = p.phase[g];
     if (phase != RP_PHASE_MOVE_READY && phase != RP_PHASE_RUNNING) return;
-    Tree<row_t> t(p, g);
+    extern __shared__ u16 s_stage[];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = p.root[g];
@@ -1394,7 +1403,8 @@ template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= p.G) return;
-    Tree<row_t> t(p, g);
+    extern __shared__ u16 s_stage[];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = NONE32;
@@ -2322,6 +2332,9 @@ template <typename T> static int dev_alloc(rp_ctx *ctx, T **out, size_t n, bool 
         if (rc_ != RP_OK) return rc_;            \
     } while (0)
 
+// kernels that can create nodes stage a node's legal moves in LDS: WAVES_PER_BLOCK runs of A actions
+#define STAGE_BYTES(d) ((size_t)WAVES_PER_BLOCK * (size_t)(d).A * sizeof(u16))
+
 static int grid_for(long long waves) { return (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
 
 static int check_device_error(rp_ctx *ctx) {
@@ -2390,7 +2403,9 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.W = cfg->W; d.H = cfg->H; d.N = cfg->N; d.A = cfg->W * cfg->N; d.G = cfg->games; d.sims = cfg->sims;
     d.cpuct = cfg->cpuct; d.seed = cfg->seed; d.tie_salt = cfg->tie_salt; d.move_rule = cfg->move_rule;
     d.node_cap = cfg->node_cap > 0 ? cfg->node_cap : cfg->sims * (cfg->N + 1) + 2;
-    d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : d.node_cap * std::min(d.A, 96) + d.A;
+    // legal moves per node: measured means are 8 of 80 actions (10x10/8), 54 of 640 (20x20/32) and 460 of 6 400 (50x50/128) -- about A / 12;
+    // the automatic size (nothing is recycled by default: the API classes may re-root anywhere) allows A / 8, at least min(A, 96)
+    d.edge_cap = cfg->edge_cap > 0 ? cfg->edge_cap : (int)std::min<int64_t>((int64_t)d.node_cap * std::max(std::min(d.A, 96), d.A / 8) + d.A, (int64_t)0x7FFF0000);
     d.vis_cap = cfg->vis_cap > 0 ? cfg->vis_cap : 6 * d.node_cap + 64;
     // level arenas: a chunk must hold the largest run (A legal moves / a visited block of up to A entries)
     auto pow2_at_least = [](int x) { int c = 1; while (c < x) c *= 2; return c; };
@@ -2446,6 +2461,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     if (d.max_examples > 0) {
         A_(d.ex_key, (size_t)d.max_examples * d.KW); A_(d.ex_wh, (size_t)d.max_examples * N * 2);
         A_(d.ex_counts, (size_t)d.max_examples * d.A); A_(d.ex_value, (size_t)d.max_examples);
+        A_(d.ex_episode, (size_t)d.max_examples); A_(d.ex_move, (size_t)d.max_examples);
     }
     std::vector<int> llo, ln, sd, ss;
     build_plan(0, d.A, llo, ln, sd, ss);
@@ -2469,6 +2485,22 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         delete ctx;
         return fail(nullptr, RP_ERR_DEVICE, "rp_create: device initialisation failed");
     }
+    if (STAGE_BYTES(d) + 8192 > 64 * 1024) {  // A > ~7 000: static + staging LDS pass the default 64 KB limit
+        const int lim = (int)(STAGE_BYTES(d) + 8192);
+        if (ctx->row64) {
+            (void)hipFuncSetAttribute((const void *)k_search<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_moves<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_set_roots<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_advance<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_pool_begin<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_search<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_moves<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_set_roots<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_advance<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+            (void)hipFuncSetAttribute((const void *)k_pool_begin<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        }
+    }
     *out = ctx;
     return RP_OK;
 }
@@ -2477,6 +2509,14 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     do {                                                                                                   \
         if ((ctx)->row64) hipLaunchKernelGGL(kernel<u64>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, (ctx)->stream, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel<u32>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, (ctx)->stream, __VA_ARGS__);              \
+        hipError_t le_ = hipGetLastError();                                                                \
+        if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of %s failed: %s", #kernel, hipGetErrorString(le_)); \
+    } while (0)
+
+#define DISPATCH_STAGED(ctx, kernel, grid, ...)                                                            \
+    do {                                                                                                   \
+        if ((ctx)->row64) hipLaunchKernelGGL(kernel<u64>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), STAGE_BYTES((ctx)->d), (ctx)->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel<u32>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), STAGE_BYTES((ctx)->d), (ctx)->stream, __VA_ARGS__);              \
         hipError_t le_ = hipGetLastError();                                                                \
         if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of %s failed: %s", #kernel, hipGetErrorString(le_)); \
     } while (0)
@@ -2603,7 +2643,7 @@ extern "C" int rp_begin_episodes(rp_ctx *ctx, int32_t first, int32_t count, cons
     HIPCHK(ctx, hipMemcpyAsync(d.total_area + first, total_area, (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d.max_h + first, mh.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d.episode + first, ids.data(), (size_t)count * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)nullptr, (const u8 *)nullptr, 1);
+    DISPATCH_STAGED(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)nullptr, (const u8 *)nullptr, 1);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
     return check_device_error(ctx);
 }
@@ -2615,7 +2655,7 @@ extern "C" int rp_set_roots(rp_ctx *ctx, int32_t first, int32_t count, const uin
     Scratch s(ctx);
     u64 *drows = s.up((const u64 *)rows, (size_t)count * d.H); NEED(drows);
     u8 *drem = s.up(remaining, (size_t)count * d.N); NEED(drem);
-    DISPATCH(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)drows, (const u8 *)drem, 0);
+    DISPATCH_STAGED(ctx, k_set_roots, grid_for(count), d, (int)first, (int)count, (const u64 *)drows, (const u8 *)drem, 0);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_device_error(ctx);
 }
@@ -2666,8 +2706,8 @@ extern "C" int rp_last_values(rp_ctx *ctx, int32_t first, int32_t count, double 
 extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
     if (!ctx) return RP_ERR_ARG;
     DP &d = ctx->d;
-    if (d.move_rule != RP_MOVE_EXTERNAL) DISPATCH(ctx, k_moves, grid_for(d.G), d);
-    DISPATCH(ctx, k_search, grid_for(d.G), d);
+    if (d.move_rule != RP_MOVE_EXTERNAL) DISPATCH_STAGED(ctx, k_moves, grid_for(d.G), d);
+    DISPATCH_STAGED(ctx, k_search, grid_for(d.G), d);
     // Without a count request nothing is synchronised and evaluator row b belongs to slot b (fixed shapes for graph capture);
     // with one, the waiting slots are listed in slot order and rows follow that list.
     d.rows_identity = (n_leaves_out || ctx->compact_rows) ? 0 : 1;
@@ -2999,7 +3039,7 @@ extern "C" int rp_advance_roots(rp_ctx *ctx, int32_t first, int32_t count, const
     const DP &d = ctx->d;
     Scratch s(ctx);
     int *dact = s.up(action, (size_t)count); NEED(dact);
-    DISPATCH(ctx, k_advance, grid_for(count), d, (int)first, (int)count, (const int *)dact);
+    DISPATCH_STAGED(ctx, k_advance, grid_for(count), d, (int)first, (int)count, (const int *)dact);
     if (ended_out) HIPCHK(ctx, hipMemcpyAsync(ended_out, d.last_outcome + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (score_out) HIPCHK(ctx, hipMemcpyAsync(score_out, d.last_score + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return check_device_error(ctx);
@@ -3123,7 +3163,7 @@ extern "C" int rp_begin_pool(rp_ctx *ctx) {
     if (!ctx) return RP_ERR_ARG;
     const DP &d = ctx->d;
     if (!d.pool_wh) return fail(ctx, RP_ERR_STATE, "rp_begin_pool: no instance pool set");
-    DISPATCH(ctx, k_pool_begin, grid_for(d.G), d);
+    DISPATCH_STAGED(ctx, k_pool_begin, grid_for(d.G), d);
     return check_device_error(ctx);
 }
 
@@ -3145,6 +3185,19 @@ extern "C" int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, fl
     if (count == 0) return RP_OK;
     const DP &d = ctx->d;
     DISPATCH(ctx, k_examples, grid_for(count), d, (long long)first, (long long)count, planes_dev, pi_dev, value_dev);
+    return RP_OK;
+}
+
+extern "C" int rp_examples_meta(rp_ctx *ctx, int64_t first, int64_t count, uint64_t *episode_id_out, int32_t *move_out) {
+    if (!ctx || first < 0 || count < 0 || !episode_id_out || !move_out) return fail(ctx, RP_ERR_ARG, "rp_examples_meta: bad argument");
+    int64_t n = 0;
+    int rc = rp_examples_count(ctx, &n);
+    if (rc != RP_OK) return rc;
+    if (first + count > n) return fail(ctx, RP_ERR_ARG, "rp_examples_meta: range [%lld,%lld) exceeds the %lld recorded examples", (long long)first, (long long)(first + count), (long long)n);
+    if (count == 0) return RP_OK;
+    HIPCHK(ctx, hipMemcpyAsync(episode_id_out, ctx->d.ex_episode + first, (size_t)count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(move_out, ctx->d.ex_move + first, (size_t)count * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RP_OK;
 }
 

@@ -5,7 +5,8 @@ for tests).  Self-play episodes shard across ranks with no data-path collective 
   * all-gather of the replay examples and episode scores (variable length: sizes first, then padded payloads), so every
     rank rebuilds the same training set and the same R2 buffer;
   * all-reduce (sum) of the FP32 gradients as ONE flat bucket per optimizer step -- 0.6-8.7 MB, latency-bound on
-    7 x 153 GB/s xGMI links, so a single message beats per-tensor calls.
+    7 x 153 GB/s xGMI links, so a single message beats per-tensor calls.  A step covers `batch_size` examples whatever the
+    rank count: one shared index stream, rank r takes every world-th index (NNetWrapper.train_tensors).
 """
 import os
 
@@ -38,17 +39,27 @@ def rank():
 
 
 def shard(n_items, rank_=None, world=None):
-    """Indices of the episodes rank `rank_` plays: i = rank, rank + world, ...  Independent of how many slots a rank
-    has, so results do not depend on the rank count."""
+    """Episodes rank `rank_` plays: a contiguous block of the iteration's episodes (sizes differ by at most one).  An episode's
+    result depends on its global index only (instance, sampling stream), never on the rank or slot that played it."""
     rank_ = rank() if rank_ is None else rank_
     world = world_size() if world is None else world
-    return list(range(rank_, n_items, world))
+    base, rem = divmod(int(n_items), world)
+    lo = rank_ * base + min(rank_, rem)
+    return list(range(lo, lo + base + (1 if rank_ < rem else 0)))
+
+
+def _host_staged():
+    """gloo moves only broadcast / all-reduce on device tensors; its all-gather needs host tensors (CPU rehearsals, tests)."""
+    return dist.get_backend() == "gloo"
 
 
 def all_gather_variable(t):
     """All-gathers tensors that differ in their first dimension; returns the concatenation in rank order."""
     if world_size() == 1:
         return t
+    dev = t.device
+    if _host_staged():
+        t = t.cpu()
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world_size())]
     dist.all_gather(sizes, n)
@@ -58,7 +69,7 @@ def all_gather_variable(t):
     pad[:t.shape[0]] = t
     out = [torch.empty_like(pad) for _ in range(world_size())]
     dist.all_gather(out, pad)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0).to(dev)
 
 
 def all_gather_examples(planes, pi, value):
@@ -70,19 +81,23 @@ def all_gather_examples(planes, pi, value):
 
 
 class FlatGradAllReduce:
-    """Gradient hook for NNetWrapper.train_tensors: one flat FP32 bucket, one all-reduce(sum), mean over ranks."""
+    """Gradient hook for NNetWrapper.train_tensors: one flat FP32 bucket, one all-reduce(sum).  Every rank's loss is already
+    divided by the FULL batch size, so the sum over ranks is the gradient of the whole batch.  Scalars passed as `extra`
+    (the two loss values) ride in the same message and come back summed."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
 
-    def __call__(self, module):
+    def __call__(self, module, extra=()):
+        extra = tuple(extra)
         if world_size() == 1:
-            return
+            return extra
         dev = self.params[0].device
-        if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        total = self.numel + len(extra)
+        if self.flat is None or self.flat.device != dev or self.flat.numel() != total:
+            self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -91,8 +106,9 @@ class FlatGradAllReduce:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
+        for k, x in enumerate(extra):
+            self.flat[off + k] = x
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(world_size())
         off = 0
         for p in self.params:
             n = p.numel()
@@ -100,6 +116,7 @@ class FlatGradAllReduce:
                 p.grad = torch.empty_like(p)
             p.grad.copy_(self.flat[off:off + n].view_as(p))
             off += n
+        return tuple(self.flat[off + k].clone() for k in range(len(extra)))
 
 
 def broadcast_parameters(module, src=0):
@@ -110,7 +127,7 @@ def broadcast_parameters(module, src=0):
 
 
 def attach(nnet_wrapper):
-    """Makes `nnet_wrapper.train*` data-parallel: identical initial weights, averaged gradients every step."""
+    """Makes `nnet_wrapper.train*` data-parallel: identical initial weights, gradients summed over the ranks' batch slices."""
     broadcast_parameters(nnet_wrapper.nnet)
     nnet_wrapper.grad_hook = FlatGradAllReduce(nnet_wrapper.nnet)
     return nnet_wrapper

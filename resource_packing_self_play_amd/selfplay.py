@@ -29,13 +29,15 @@ class _Group:
         self.G = games
         self.stream = torch.cuda.Stream(owner.device)
         self.eng = _lib.Engine(owner.W, owner.H, owner.N, games, int(owner.args.numMCTSSims), cpuct=float(owner.args.cpuct),
-                               alpha=float(owner.args.alpha), move_rule=owner.move_rule, seed=seed, tie_salt=seed ^ 0x5DEECE66D,
+                               alpha=float(owner.args.alpha), move_rule=owner.move_rule, seed=seed,
+                               tie_salt=(seed ^ 0x5DEECE66D) if owner.tie_salt is None else int(owner.tie_salt),
                                node_cap=owner.node_cap, edge_cap=owner.edge_cap, device=owner.device.index or 0,
                                stream=self.stream.cuda_stream, auto_restart=1, max_examples=owner.max_examples_per_group,
                                vis_cap=owner.vis_cap, reclaim=1 if owner.reclaim else 0)
         self.eng.set_step_cap(owner.step_cap)
         self.eng.set_compact_rows(owner.compact_rows)
         self.use_stem = owner.use_stem
+        self.host_evaluator = owner.host_evaluator
         if self.use_stem:  # the engine computes the first conv + pool itself: no plane tensor at all
             self.channels_last = owner.channels_last
             self.resblock_kernel = owner.resblock_kernel
@@ -62,6 +64,13 @@ class _Group:
         return nnet.predict_batch(self.planes)
 
     def wave_eager(self, nnet):
+        if self.host_evaluator is not None:  # generic evaluator on the host: leaf states out, (pi, v) back (like nnet.predict, MCTS_bpp.py:87)
+            n = self.eng.search_step()
+            if n:
+                rows, rem, slots = self.eng.leaf_states(n)
+                pi, v = self.host_evaluator(rows, rem, slots)
+                self.eng.commit_eval_host(pi, v)
+            return
         self.eng.search_step(sync=False)
         if self.use_stem:
             self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None, self.channels_last)
@@ -73,7 +82,11 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, compact_rows=True, channels_last=True, resblock_kernel=True, device=None):
+                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, compact_rows=True, channels_last=True, resblock_kernel=True, device=None,
+                 tie_salt=None, host_evaluator=None):
+        """host_evaluator: optional callable (rows [n][H] uint64, remaining [n][N] uint8, slots [n]) -> (pi [n][A] float32, v [n]
+        float32) that replaces the CNN -- any object with the reference's `predict` contract can sit behind it; the waves then run
+        eagerly with one host round trip each.  tie_salt: salt of the deterministic `r == bl` tie (default: derived from seed)."""
         self.game, self.nnet, self.args = game, nnet, args
         self.W, self.H, self.N = game.bin_width, game.bin_height, game.num_items
         self.A = self.W * self.N
@@ -86,7 +99,8 @@ class BatchedSelfPlay:
         self.reclaim, self.vis_cap = bool(reclaim), int(vis_cap)
         self.compact_rows = bool(compact_rows)  # evaluator rows = the waiting slots only, listed on the device (rp_set_compact_rows)
         self.max_examples_per_group = (int(max_examples) + groups - 1) // groups if max_examples else 0
-        self.use_graph = use_graph
+        self.tie_salt, self.host_evaluator = tie_salt, host_evaluator
+        self.use_graph = bool(use_graph) and host_evaluator is None
         self.use_stem = bool(use_stem)
         self.fuse_elementwise = bool(fuse_elementwise) and self.use_stem
         self.dense_small_convs = bool(dense_small_convs)
@@ -96,7 +110,9 @@ class BatchedSelfPlay:
         if self.channels_last:  # convolution weights in NHWC too, so MIOpen never converts per call
             nnet.nnet.to(memory_format=torch.channels_last)
         sizes = [self.G // groups + (1 if k < self.G % groups else 0) for k in range(groups)]
-        self.groups = [_Group(self, k, sizes[k], (seed * 1315423911 + k) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
+        # every group (and every rank) samples with the SAME seed: a move's draw depends on (seed, global episode id, move) only,
+        # so episodes do not depend on how many groups or ranks share the pool
+        self.groups = [_Group(self, k, sizes[k], int(seed) & 0x7FFFFFFFFFFFFFFF) for k in range(groups)]
         self.steps = 0
         self.first_id = 0
 
@@ -118,6 +134,8 @@ class BatchedSelfPlay:
         """Warms the evaluator up (MIOpen picks its kernels on the first calls) and captures every group's wave -- the
         engine's kernels and the CNN's -- into one HIP graph each, so a wave costs one graph launch instead of ~40 kernel
         launches."""
+        if self.host_evaluator is not None:
+            return
         if self.fuse_elementwise and self.dense_small_convs:
             self.nnet.refresh_fused()
         if not self.use_graph:
@@ -165,24 +183,34 @@ class BatchedSelfPlay:
         self.invalidate_graph()
 
     # ---- whole pools -------------------------------------------------------------------------------
+    def _blocks(self, n):
+        """Contiguous block of the pool per group: [(lo, hi)]; instance i has episode id first_id + i."""
+        k = len(self.groups)
+        base, rem = divmod(int(n), k)
+        out, lo = [], 0
+        for g in range(k):
+            hi = lo + base + (1 if g < rem else 0)
+            out.append((lo, hi)); lo = hi
+        return out
+
     def start(self, item_wh, total_area, rewards_list=(), first_id=0):
-        """Instance i of the pool goes to group i % groups; its episode id is first_id + i."""
+        """The pool is cut into one contiguous block per group; instance i's episode id is first_id + i."""
         item_wh = np.ascontiguousarray(item_wh, dtype=np.uint8)
         total_area = np.ascontiguousarray(total_area, dtype=np.int32)
         buf = np.asarray(list(rewards_list), dtype=np.float64)
         self.first_id = int(first_id)
         self.n_instances = item_wh.shape[0]
-        k = len(self.groups)
         torch.cuda.synchronize(self.device)  # the evaluator's weights may just have been trained on another stream
-        if self.fuse_elementwise and self.dense_small_convs:
+        if self.host_evaluator is None and self.fuse_elementwise and self.dense_small_convs:
             self.nnet.refresh_fused()
             torch.cuda.synchronize(self.device)
-        for g in self.groups:
-            wh_g = np.ascontiguousarray(item_wh[g.index::k]); area_g = np.ascontiguousarray(total_area[g.index::k])
-            with torch.cuda.stream(g.stream):
-                g.refresh_weights(self.nnet)  # stem tables follow in-place weight updates
+        for g, (lo, hi) in zip(self.groups, self._blocks(self.n_instances)):
+            wh_g = np.ascontiguousarray(item_wh[lo:hi]); area_g = np.ascontiguousarray(total_area[lo:hi])
+            if self.host_evaluator is None:
+                with torch.cuda.stream(g.stream):
+                    g.refresh_weights(self.nnet)  # stem tables follow in-place weight updates
             g.eng.set_rank_buffer(buf)
-            g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), 0))
+            g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), self.first_id + lo))
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
     def start_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None):
@@ -192,16 +220,16 @@ class BatchedSelfPlay:
         buf = np.asarray(list(rewards_list), dtype=np.float64)
         self.first_id = int(first_id)
         self.n_instances = seeds.shape[0]
-        k = len(self.groups)
         torch.cuda.synchronize(self.device)
-        if self.fuse_elementwise and self.dense_small_convs:
+        if self.host_evaluator is None and self.fuse_elementwise and self.dense_small_convs:
             self.nnet.refresh_fused()
             torch.cuda.synchronize(self.device)
-        for g in self.groups:
-            with torch.cuda.stream(g.stream):
-                g.refresh_weights(self.nnet)
+        for g, (lo, hi) in zip(self.groups, self._blocks(self.n_instances)):
+            if self.host_evaluator is None:
+                with torch.cuda.stream(g.stream):
+                    g.refresh_weights(self.nnet)
             g.eng.set_rank_buffer(buf)
-            g.eng.set_instance_pool_seeds(np.ascontiguousarray(seeds[g.index::k]), self.W, bin_h or self.H, 0)
+            g.eng.set_instance_pool_seeds(np.ascontiguousarray(seeds[lo:hi]), self.W, bin_h or self.H, self.first_id + lo)
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
     def active(self):
@@ -213,11 +241,10 @@ class BatchedSelfPlay:
 
     def pop_finished(self):
         """(episode ids, outcomes, scores, moves) of the episodes finished since the last call, sorted by id."""
-        k = len(self.groups)
         parts = []
         for g in self.groups:
             ids, oc, sc, mv = g.eng.pop_finished()
-            parts.append((ids.astype(np.int64) * k + g.index + self.first_id, oc, sc, mv))
+            parts.append((ids.astype(np.int64), oc, sc, mv))
         ids = np.concatenate([p[0] for p in parts]); order = np.argsort(ids, kind="stable")
         return tuple(np.concatenate([p[j] for p in parts])[order] for j in range(4))
 
@@ -259,9 +286,11 @@ class BatchedSelfPlay:
         return ids, outcome, score, moves, stats
 
     # ---- replay ---------------------------------------------------------------------------------
-    def examples(self):
-        """(planes [E, N+1, H, W], pi [E, A], value [E]) float32 device tensors of everything recorded so far."""
-        out = []
+    def examples(self, with_meta=False):
+        """(planes [E, N+1, H, W], pi [E, A], value [E]) float32 device tensors of everything recorded so far, in the reference's
+        order: episode by episode, move by move (CoachBPP.py:80,133) -- the device buffer itself fills in completion order.
+        with_meta: also (episode ids [E] int64, move numbers [E] int32) as numpy arrays."""
+        out, eps, mvs = [], [], []
         for g in self.groups:
             n = _lib._i64(0)
             g.eng._ck(g.eng.L.rp_examples_count(g.eng.h, _lib.C.byref(n)))
@@ -270,13 +299,20 @@ class BatchedSelfPlay:
             planes = torch.empty((e, self.N + 1, self.H, self.W), dtype=torch.float32, device=self.device)
             pi = torch.empty((e, self.A), dtype=torch.float32, device=self.device)
             value = torch.empty((e,), dtype=torch.float32, device=self.device)
+            ep = np.empty(e, np.uint64); mv = np.empty(e, np.int32)
             torch.cuda.synchronize(self.device)
             if e:
                 g.eng._ck(g.eng.L.rp_examples_tensors(g.eng.h, 0, e, _lib.C.c_void_p(planes.data_ptr()), _lib.C.c_void_p(pi.data_ptr()),
                                                       _lib.C.c_void_p(value.data_ptr())))
+                g.eng._ck(g.eng.L.rp_examples_meta(g.eng.h, 0, e, _lib._ptr(ep), _lib._ptr(mv)))
             out.append((planes, pi, value))
+            eps.append(ep.astype(np.int64)); mvs.append(mv)
         torch.cuda.synchronize(self.device)
-        return tuple(torch.cat([o[j] for o in out]) for j in range(3))
+        ep, mv = np.concatenate(eps), np.concatenate(mvs)
+        order = np.lexsort((mv, ep))
+        idx = torch.as_tensor(order, device=self.device)
+        res = tuple(torch.cat([o[j] for o in out]).index_select(0, idx) for j in range(3))
+        return res + (ep[order], mv[order]) if with_meta else res
 
     def clear_examples(self):
         for g in self.groups:

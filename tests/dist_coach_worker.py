@@ -1,0 +1,56 @@
+"""One rank of tests/test_gpu_coach.py::test_two_ranks_play_and_train_like_one (launched with the torchrun environment).
+usage: dist_coach_worker.py <out dir> <world>"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main(out_dir, world):
+    import torch
+    from engine_util import host_evaluator
+    from resource_packing_self_play_amd import _lib
+    from resource_packing_self_play_amd import distributed as rdist
+    from resource_packing_self_play_amd.CoachBPP import CoachBPP
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame, ItemsGenerator
+    from resource_packing_self_play_amd.binpacking.pytorch.NNet import NNetWrapper
+    from resource_packing_self_play_amd.utils import dotdict
+    rank, w, local = rdist.init_from_env()
+    assert w == int(world)
+    torch.cuda.set_device(local)
+    W, H, N, salt = 10, 10, 8, 23
+    args = dotdict(numMCTSSims=16, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=2, batch_size=8, numIters=1, numEps=7,
+                   iterStepThreshold=5, binH_min=6, binH=10, numScoresForRank=20, numItersForTrainExamplesHistory=5, maxlenOfQueue=200000,
+                   numItems=N, checkpoint=os.path.join(out_dir, "ck_w%s_r%d" % (world, rank)), seed=3, use_graph=False, groups=1, tie_salt=salt,
+                   host_evaluator=host_evaluator(lambda s: "hashed", W * N, lambda s: salt))
+    game = BinPackingGame(W, H, N, 1)
+    torch.manual_seed(100 + rank)  # ranks start from different weights on purpose: learn()'s attach broadcasts rank 0's
+    nnet = NNetWrapper(game, args)
+    if rank == 0 or w == 1:
+        torch.manual_seed(100)
+        nnet = NNetWrapper(game, args)
+    gen = ItemsGenerator(W, H, N)
+    coach = CoachBPP(game, nnet, gen.items_generator(100), W * H, gen, args, saved_rewards_list=[0.7, 0.8, 0.85, 0.9, 1.0])
+    seeds = [11, 22, 33, 44, 55, 66, 77]
+    scores, (planes, pi, value) = coach.selfPlayIteration(1, draws=(9, seeds))  # sampled moves: the draw depends on (seed, episode, move) only
+    # one full learn() iteration with pinned draws: self-play, R2 bookkeeping, data-parallel training from rank 0's seed
+    coach.rewards_list = [0.7, 0.8, 0.85, 0.9, 1.0]
+    coach.drawIteration = lambda: (8, [5, 6, 7, 8, 9, 10, 11])
+    np.random.seed(1234)
+    if w == 1:  # with several ranks rank 0's first draw seeds the shared index stream of train_tensors: do the same by hand
+        np.random.seed(int(np.random.randint(1 << 31)))
+    coach.learn()
+    weights = {"w__" + k: t.detach().cpu().numpy() for k, t in nnet.nnet.state_dict().items()}
+    np.savez(os.path.join(out_dir, "coach_w%s_r%d.npz" % (world, rank)), scores=np.array(scores), planes=planes.cpu().numpy().astype(np.uint8),
+             pi=pi.cpu().numpy(), value=value.cpu().numpy(), scores2=np.array(coach.iteration_scores[-1]), **weights)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

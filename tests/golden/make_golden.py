@@ -36,6 +36,7 @@ for name in ("torchvision", "wandb"):
         mod = types.ModuleType(name)
         mod.datasets = types.ModuleType(name + ".datasets")
         mod.transforms = types.ModuleType(name + ".transforms")
+        mod.log = lambda *a, **k: None
         sys.modules[name] = mod
         sys.modules[name + ".datasets"] = mod.datasets
         sys.modules[name + ".transforms"] = mod.transforms
@@ -521,6 +522,124 @@ def gen_nnet_c5():
     print("wrote nnet_c5_seed0.npz", np.stack(pis).shape, digest[:16])
 
 
+def gen_coach():
+    """Two iterations of the reference's CoachBPP.learn (CoachBPP.py:101-196) -- the second one greedy (iterStepThreshold = 1, :132) --
+    with everything random pinned: np.random.seed() without an argument (the OS-entropy reseeds at :86 and :117) is ignored after
+    one np.random.seed(4242), np.random.choice picks the lowest index of the largest probability (:87; MCTS_bpp.py:46 picks the
+    lowest best action), the `r == bl` tie draws ev.tie_value(state) (TieGame), the evaluator is the hashed table evaluator, and
+    nnet.train / save_checkpoint / wandb.log are recorded no-ops.  Stored per episode: generator seed, generator height, the R2
+    buffer as it stood BEFORE the episode (the reference appends after every episode, :134), the (state, pi, r) tuples (:99) and
+    the score; per iteration: the buffer after the trim (:136-139) and the logged metrics (:143-147)."""
+    import tempfile
+    import wandb
+    from CoachBPP import CoachBPP
+    w, h, n, sims, salt = 10, 10, 8, 20, 17
+
+    class CoachNet:
+        def __init__(self, game, args):
+            self.game, self.kind, self.salt, self.trained = game, args.table_kind, args.table_salt, []
+        def predict(self, state):
+            rows, rem, _, _ = ev.pack_state(state)
+            return ev.table_eval(self.kind, rows, rem, self.game.getActionSize(), self.salt)
+        def train(self, examples):
+            self.trained.append(len(examples))
+        def save_checkpoint(self, folder, filename):
+            pass
+
+    g = TieGame(w, h, n, 1)
+    g.tie_salt = salt
+    tmp = tempfile.mkdtemp()
+    args = Args(numIters=2, numEps=8, iterStepThreshold=1, maxlenOfQueue=200000, numMCTSSims=sims, cpuct=1, alpha=0.75, seed=100,
+                numItersForTrainExamplesHistory=50, numScoresForRank=14, binH_min=6, binH=10, numItems=n, checkpoint=tmp,
+                table_kind="hashed", table_salt=salt)
+    gen = ItemsGenerator(w, h, n)
+    # distinct values around the 75 % quantile: the threshold bl moves when an append leaves floor(len * alpha) unchanged
+    initial = [0.5, 0.6, 0.7, 0.75, 0.78, 0.8, 0.8125, 0.875, 0.9, 1.0]
+    coach = CoachBPP(g, CoachNet(g, args), gen.items_generator(args.seed), w * h, gen, args, saved_rewards_list=list(initial))
+    episodes, seeds, logged = [], [], []
+    orig_exec, orig_gen = coach.executeEpisode, gen.items_generator
+    def rec_exec(greedy=False):
+        before = [float(x) for x in coach.rewards_list]
+        ex = orig_exec(greedy)
+        episodes.append(dict(greedy=bool(greedy), seed=seeds[-1], bin_height=int(gen.bin_height), total_area=int(coach.items_total_area),
+                             items=np.array(coach.items_list)[:, :2].astype(np.uint8), before=before, score=float(coach.ep_score), examples=ex))
+        return ex
+    def rec_gen(seed):
+        seeds.append(int(seed))
+        return orig_gen(seed)
+    coach.executeEpisode, gen.items_generator = rec_exec, rec_gen
+    orig_seed, orig_choice, orig_log = np.random.seed, np.random.choice, getattr(wandb, "log", None)
+    def fake_seed(seed=None):
+        if seed is not None:
+            orig_seed(seed)
+    def fake_choice(a, size=None, replace=True, p=None):
+        idx = int(np.argmax(np.asarray(p))) if p is not None else 0
+        return idx if isinstance(a, (int, np.integer)) else np.asarray(a).reshape(-1)[idx]
+    wandb.log = lambda d, step=None: logged.append((int(step), {k: float(v) for k, v in d.items()}))
+    np.random.seed(4242)
+    np.random.seed, np.random.choice = fake_seed, fake_choice
+    try:
+        coach.learn()
+    finally:
+        np.random.seed, np.random.choice = orig_seed, orig_choice
+        if orig_log is not None:
+            wandb.log = orig_log
+    E = args.numEps
+    assert len(episodes) == 2 * E and coach.nnet.trained and len(coach.rewards_list) <= args.numScoresForRank
+    ex_ep, ex_rows, ex_rem, ex_pi, ex_r = [], [], [], [], []
+    for k, e in enumerate(episodes):
+        for state, pi, r in e["examples"]:
+            rows, rem, _, _ = ev.pack_state(state)
+            ex_ep.append(k); ex_rows.append(rows); ex_rem.append(rem); ex_pi.append(np.asarray(pi, np.float64)); ex_r.append(int(r))
+    blen = max(len(e["before"]) for e in episodes)
+    before = np.full((len(episodes), blen), np.nan)
+    for k, e in enumerate(episodes):
+        before[k, :len(e["before"])] = e["before"]
+    metrics = {}
+    for step, dd in logged:
+        metrics.setdefault(step, {}).update(dd)
+    np.savez_compressed(os.path.join(HERE, "coach_c1.npz"), meta=json.dumps(META), W=w, H=h, N=n, sims=sims, salt=salt, kind="hashed", alpha=args.alpha,
+                        numEps=E, numIters=2, iterStepThreshold=1, numScoresForRank=args.numScoresForRank, binH_min=args.binH_min, binH=args.binH,
+                        initial=np.array(initial), ep_seed=np.array([e["seed"] for e in episodes], np.int64),
+                        ep_bin_height=np.array([e["bin_height"] for e in episodes], np.int32), ep_area=np.array([e["total_area"] for e in episodes], np.int32),
+                        ep_items=np.stack([e["items"] for e in episodes]), ep_greedy=np.array([e["greedy"] for e in episodes]),
+                        ep_score=np.array([e["score"] for e in episodes]), ep_before=before, ep_before_len=np.array([len(e["before"]) for e in episodes], np.int32),
+                        after_iter1=np.array(episodes[E]["before"]), after_iter2=np.array([float(x) for x in coach.rewards_list]),
+                        ex_ep=np.array(ex_ep, np.int32), ex_rows=np.stack(ex_rows), ex_rem=np.stack(ex_rem), ex_pi=np.stack(ex_pi), ex_r=np.array(ex_r, np.int8),
+                        trained_on=np.array(coach.nnet.trained, np.int64), metrics=json.dumps(metrics))
+    def bl_of(buf):
+        sb = np.sort(buf)
+        return float(sb[int(np.floor(len(sb) * args.alpha)) - 1])
+    for it in range(2):
+        eps = episodes[it * E:(it + 1) * E]
+        print("iteration %d: bin_height %d, scores %s" % (it + 1, eps[0]["bin_height"], [round(e["score"], 4) for e in eps]))
+        print("   bl before each episode: %s  (snapshot bl %.4f)" % ([round(bl_of(e["before"]), 4) for e in eps], bl_of(eps[0]["before"])))
+        print("   r per episode: %s" % [e["examples"][0][2] for e in eps])
+    print("wrote coach_c1.npz: %d examples, trained on %s, metrics %s" % (len(ex_ep), coach.nnet.trained, metrics))
+
+
+def gen_train_grads():
+    """Gradients of the reference's loss (NNet.py:87-91: loss_pi + loss_v) on the fixed batch of train_c2.npz (its first 8 examples)
+    at the stored initial weights, through the reference's own module.  Adam turns a gradient that is exactly zero on the CPU but
+    1e-9 of rounding noise elsewhere into a step of ~lr, so weights after training are comparable across back ends only where
+    the gradient is above noise; the gradients themselves are comparable everywhere."""
+    import torch
+    from binpacking.pytorch.NNet import NNetWrapper
+    d = np.load(os.path.join(HERE, "train_c2.npz"))
+    w, h, n = int(d["W"]), int(d["H"]), int(d["N"])
+    g = BinPackingGame(w, h, n, 1)
+    net = NNetWrapper(g, Args(cuda=False, num_items=n, num_bins=1, epochs=1, batch_size=8))
+    net.nnet.load_state_dict({k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("i__")})
+    boards = torch.FloatTensor(d["planes"][:8].astype(np.float64))
+    tp = torch.FloatTensor(d["pi"][:8]); tv = torch.FloatTensor(d["v"][:8].astype(np.float64))
+    net.nnet.train()
+    op, ov = net.nnet(boards)
+    (net.loss_pi(tp, op) + net.loss_v(tv, ov)).backward()
+    grads = {"g__" + k: p.grad.detach().numpy().copy() for k, p in net.nnet.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "train_c2_grads.npz"), meta=json.dumps(dict(META, torch=torch.__version__)), **grads)
+    print("wrote train_c2_grads.npz", len(grads), max(float(np.abs(v).max()) for v in grads.values()))
+
+
 def gen_train():
     """NNetWrapper.train (NNet.py:27-67) for a few steps on CPU from seeded weights and examples: final weights and
     the loss values of loss_pi / loss_v (NNet.py:87-91) on a fixed batch."""
@@ -569,7 +688,7 @@ def gen_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet", "nnet_c5", "nnet64", "train"]
+    which = sys.argv[1:] or ["items", "rules", "reward", "q", "mcts", "nnet", "nnet_c5", "nnet64", "coach", "train", "train_grads"]
     if "items" in which: gen_items()
     if "rules" in which: gen_game_rules()
     if "reward" in which: gen_ranked_reward()
@@ -578,4 +697,6 @@ if __name__ == "__main__":
     if "nnet" in which: gen_nnet()
     if "nnet_c5" in which: gen_nnet_c5()
     if "nnet64" in which: gen_nnet_f64()
+    if "coach" in which: gen_coach()
     if "train" in which: gen_train()
+    if "train_grads" in which: gen_train_grads()

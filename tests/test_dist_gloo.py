@@ -19,8 +19,8 @@ def _worker(rank, world, port, out_dir):
     from resource_packing_self_play_amd import distributed as rdist
     r, w, _ = rdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and rdist.rank() == rank and rdist.world_size() == world
-    # episode sharding is a partition that does not depend on slot counts
-    assert rdist.shard(7) == list(range(rank, 7, world))
+    # episode sharding is a partition into contiguous blocks that does not depend on slot counts
+    assert rdist.shard(7) == ([0, 1, 2, 3] if rank == 0 else [4, 5, 6]) and rdist.shard(1) == ([0] if rank == 0 else [])
     # variable-length all-gather keeps rank order
     t = torch.arange(3 + 2 * rank, dtype=torch.float32).reshape(-1, 1) + 100 * rank
     g = rdist.all_gather_variable(t)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     P, Pi, V = rdist.all_gather_examples(planes, pi, val)
     assert P.shape[0] == sum(2 + k for k in range(world)) and P.dtype == torch.float32
     assert torch.equal(P[sum(2 + k for k in range(rank)):][:2 + rank], planes) and V.tolist() == sum([[k + 1.0] * (2 + k) for k in range(world)], [])
-    # data-parallel step: averaged gradients of two half batches == gradient of the full batch
+    # data-parallel step: summed gradients of two half batches, each divided by the FULL batch size == gradient of the full batch
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
     class Wrap: pass
@@ -42,15 +42,39 @@ def _worker(rank, world, port, out_dir):
     rdist.attach(wr)
     x = torch.arange(48, dtype=torch.float32).reshape(8, 6) / 10; y = torch.arange(16, dtype=torch.float32).reshape(8, 2) / 7
     half = slice(4 * rank, 4 * rank + 4)
-    loss = ((model(x[half]) - y[half]) ** 2).sum() / 4
+    loss = ((model(x[half]) - y[half]) ** 2).sum() / 8
     loss.backward()
-    wr.grad_hook(model)
+    extra = wr.grad_hook(model, (loss.detach(),))
     ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
     torch.manual_seed(0)
     ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
     (((ref(x) - y) ** 2).sum() / 8).backward()
+    full = ((ref(x) - y) ** 2).sum() / 8
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, atol=1e-6)
+    assert abs(float(extra[0]) - float(full)) < 1e-6  # the loss values ride in the same message and come back summed
+    # NNetWrapper.train_tensors on two ranks == the single-process schedule on the same index stream (NNet.py:27-67)
+    import numpy as np
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import BinPackingGame
+    from resource_packing_self_play_amd.binpacking.pytorch.NNet import NNetWrapper
+    from resource_packing_self_play_amd.utils import dotdict
+    args = dotdict(cuda=False, num_items=4, num_bins=1, epochs=2, batch_size=6)
+    game = BinPackingGame(6, 6, 4, 1)
+    torch.manual_seed(11 + rank)  # different initial weights per rank: attach() must make them rank 0's
+    net = NNetWrapper(game, args)
+    rdist.attach(net)
+    gen = torch.Generator().manual_seed(3)
+    planes = (torch.rand(20, 5, 6, 6, generator=gen) < 0.4).float(); tpi = torch.softmax(torch.randn(20, 24, generator=gen), dim=1)
+    tv = torch.sign(torch.randn(20, generator=gen))
+    np.random.seed(5)  # rank 0's next draw seeds the shared index stream
+    hist = net.train_tensors(planes, tpi, tv)
+    torch.manual_seed(11)
+    solo = NNetWrapper(game, args)
+    np.random.seed(5); np.random.seed(int(np.random.randint(1 << 31)))
+    hist_solo = solo.train_tensors(planes, tpi, tv)
+    for (k, a), (_, b) in zip(net.nnet.state_dict().items(), solo.nnet.state_dict().items()):
+        assert torch.allclose(a, b, atol=2e-6), k
+    assert np.allclose(np.array(hist), np.array(hist_solo), atol=1e-5)
     dist.barrier()
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
