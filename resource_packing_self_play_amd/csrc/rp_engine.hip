@@ -1790,12 +1790,14 @@ __global__ void __launch_bounds__(256) k_nn_value_head(const float4 *__restrict_
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define RB_STRIDE 17
 #define RB_TILES 7
-// fragment order of a [16][16][3][3] weight: frag[s][lane] = W[co = lane & 15][ci = 4 * (s & 3) + (lane >> 4)][tap = s >> 2]
+// fragment order of a [16][16][3][3] weight: k-step s = 4 * tap + j multiplies input channel ci = 4 * (lane >> 4) + j, so the four
+// A values a lane needs for one tap are four CONSECUTIVE channels of one pixel (one 16-byte LDS read) and the four B values are
+// one 16-byte load:  frag[tap][lane][j] = W[co = lane & 15][ci = 4 * (lane >> 4) + j][tap]
 __global__ void k_pack_conv16(const float *w, float *frag) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 36 * 64) return;
-    int s = i >> 6, l = i & 63;
-    int co = l & 15, ci = 4 * (s & 3) + (l >> 4), tap = s >> 2;
+    int j = i & 3, l = (i >> 2) & 63, tap = i >> 8;
+    int co = l & 15, ci = 4 * (l >> 4) + j;
     frag[i] = w[(co * 16 + ci) * 9 + tap];
 }
 // One convolution over NT pixel tiles starting at tile0 (NT is a compile-time count: no predicates inside the MFMA stream).
@@ -1810,7 +1812,7 @@ __device__ __forceinline__ void rb_conv_tiles(const float *img, const float (&bf
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int m = (tile0 + t) * 16 + (lane & 15);
-        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+        abase[t] = ptab[m < PIX ? m : 0] - (PW + 1) * RB_STRIDE + 4 * (lane >> 4);  // top-left tap of the 3x3 window, this lane's channel quad
         acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // software pipeline: the A fragments of k-step s+1 are read from LDS while the matrix cores work on step s
@@ -1821,7 +1823,7 @@ __device__ __forceinline__ void rb_conv_tiles(const float *img, const float (&bf
     for (int s = 0; s < 36; ++s) {
         if (s + 1 < 36) {
             const int tap = (s + 1) >> 2, dr = tap / 3, dx = tap - 3 * dr;
-            const int off = (dr * PW + dx) * RB_STRIDE + 4 * ((s + 1) & 3);
+            const int off = (dr * PW + dx) * RB_STRIDE + ((s + 1) & 3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
         }
@@ -1873,7 +1875,7 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
     for (int i = lane; i < 2 * IMG; i += 64) img0[i] = 0.f;  // borders stay zero for the whole launch
     float bf0[36], bf1[36];
 #pragma unroll
-    for (int s = 0; s < 36; ++s) { bf0[s] = frag0[s * 64 + lane]; bf1[s] = frag1[s * 64 + lane]; }
+    for (int s = 0; s < 36; ++s) { bf0[s] = frag0[((s >> 2) * 64 + lane) * 4 + (s & 3)]; bf1[s] = frag1[((s >> 2) * 64 + lane) * 4 + (s & 3)]; }
     const float bias0v = bias0[lane & 15], bias1v = bias1[lane & 15];
     const int ntiles_all = (PIX + 15) >> 4;
     __syncthreads();
@@ -1898,139 +1900,183 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
 // accumulators in registers, so a convolution's output overwrites its own input image once its last fragment has been read;
 // the first block's output y1 stays in registers as the second block's skip operand.  Per leaf HBM sees one read of x (plus
 // an L2-hot re-read in accumulator layout) and one write of the result -- the intermediate block output, its ReLU copy and the
-// second kernel's launch tail are gone.  B fragments (36 VGPRs) are re-read from L2 per convolution to leave room for 3 waves
-// per SIMD.  frag = [4][36][64], bias = [4][16] in execution order (b0c0, b0c1, b1c0, b1c1).
+// second kernel's launch tail are gone.
+//
+// The matrix product is taken TRANSPOSED: A = weights (rows = 16 output channels), B = pixels (columns = 16 pixels of a tile), so a
+// lane's four accumulator values are four CONSECUTIVE channels (4 * (lane >> 4) ..) of ONE pixel (lane & 15) -- 16 contiguous bytes of
+// the channels-last image.  Everything a lane touches then has that shape: x arrives as 16-byte loads in exactly this layout, an
+// epilogue is bias + ReLU + one ds_write_b128 per tile, the skip operands (x, then y1) stay in registers and are added to the
+// accumulators directly, the result leaves as 16-byte stores (1 KB per instruction).  With output rows = pixels the same epilogues
+// needed a table lookup and a 4-byte LDS write per value, a re-read of x in accumulator layout (28 scattered 4-byte loads: 11 k cycles
+// per leaf) and 4-byte output stores (13 k cycles per leaf: store-issue bound).
+//
+// The MFMA stream is scheduled by hand, one TAP (four k-steps) at a time: with the channel-quad fragment order a lane's pixel operands
+// of a tap are one ds_read_b128 per tile (pixel stride 20 floats keeps them 16-byte aligned) and its weight operands one 16-byte load
+// from L2 through a buffer resource (one address register for all 36 loads of a kernel; flat pointers make the compiler build and
+// hoist a 64-bit address per load).  Weights run two taps ahead -- across convolutions too, so a convolution never starts by waiting for
+// L2 -- and the pixel operands one tap ahead IN PLACE: tile t's fragment of the next tap is requested right behind the last MFMA
+// that reads the current one, six MFMAs (~190 cycles) before its first use.  sched_barriers pin that order: left alone the compiler
+// pairs the LDS reads of two k-steps, waits for them on the spot and issues the two dependent MFMAs back to back.
+// frag = [4][9][64] float4, bias = [4][16] in execution order (b0c0, b0c1, b1c0, b1c1).
+#ifndef RS_STRIDE
+#define RS_STRIDE 20
+#endif
 #ifndef RS_LB
 #define RS_LB 2
 #endif
-#ifndef RS_SCHED
-#define RS_SCHED 0
-#endif
+#define RS_BUF_FLAGS 0x00020000
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 rs_load_b(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+// One 3x3 convolution 16 -> 16 over NT pixel tiles.  wq: weight fragments of taps (tap, tap + 1) on entry -- taps 0 and 1 of the NEXT
+// convolution (byte offset fnext) on exit.
 template <int NT>
-__device__ __forceinline__ void rs_conv(const float *img, const float *__restrict__ frag, int PW, const int (&abase)[NT], f32x4 (&acc)[NT]) {
-    const int lane = lane_id();
-    constexpr int PF = 8;  // B fragments in flight: k-step s + PF is loaded from L2 while step s feeds the matrix cores
-    float bq[PF];
+__device__ __forceinline__ void rs_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT],
+                                        f32x4 (&wq)[3]) {
+    const int voff = lane_id() * 16;
+    f32x4 a[NT];
 #pragma unroll
-    for (int s = 0; s < PF; ++s) bq[s] = frag[s * 64 + lane];
-    float a_cur[NT], a_nxt[NT];
+    for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; a[t] = *(const f32x4 *)(img + abase[t]); }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
+    for (int tap = 0; tap < 9; ++tap) {
+        wq[(tap + 2) % 3] = rs_load_b(frs, voff, tap + 2 < 9 ? fbase + (tap + 2) * 1024 : fnext + (tap + 2 - 9) * 1024);
+        const f32x4 w = wq[tap % 3];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 36; ++s) {
-        if (s + 1 < 36) {
-            const int tap = (s + 1) >> 2, dr = tap / 3, dx = tap - 3 * dr;
-            const int off = (dr * PW + dx) * RB_STRIDE + 4 * ((s + 1) & 3);
+        for (int j = 0; j < 3; ++j) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], a[t][j], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const float b = bq[s % PF];
-        if (s + PF < 36) bq[s % PF] = frag[(s + PF) * 64 + lane];
+        const int dr = (tap + 1) / 3, dx = (tap + 1) - 3 * dr;
+        const int off = (dr * PW + dx) * RS_STRIDE;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
-#if RS_SCHED
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at one k-step
-#endif
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], a[t][3], acc[t], 0, 0, 0);
+            if (tap + 1 < 9) a[t] = *(const f32x4 *)(img + abase[t] + off);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
-template <int NT, bool LOOP>
+__device__ __forceinline__ f32x4 rs_relu(f32x4 v) { return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+// Persistent waves: grid = as many workgroups as stay resident; a wave loops over tasks (IMGW leaves each).  Tables and zero borders
+// are set up once; the next task's x is staged into the image right behind this task's output stores and the x after that is
+// requested then, so it lands in registers during the four convolutions.  Nothing in the task loop branches on data: rows past the
+// wave's pixels write to a dummy pixel, rows past the task's end read zeros and their stores are dropped by the buffer bounds check.
+template <int NT>
 __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                            float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
                                                            const int *__restrict__ nrows_dev) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    // the wave index as a scalar: everything derived from it (task numbers, buffer resources) is then provably wave-uniform; a
+    // resource the compiler takes for divergent costs a waterfall loop around every buffer load and store
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }  // only the first *nrows_dev rows hold leaves (compact rows)
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE, MP = IMGW * PIX;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RS_STRIDE, MP = IMGW * PIX, WAVE_F = IMGW * IMG + RS_STRIDE;
     int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
-    float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
+    float *img = rb_lds + 16 * NT + (size_t)wv * WAVE_F;
     for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
-        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * RB_STRIDE : 0;
+        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * RS_STRIDE : 0;
     }
-    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;  // borders (and missing leaves of the last group) stay zero
+    {
+        float4 *z4 = (float4 *)img;
+        for (int i = lane; i < WAVE_F / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // borders (and missing leaves of the last group) stay zero
+    }
     __syncthreads();
-    // LOOP: persistent waves -- the next task's x is requested before this task's four convolutions and lands in registers meanwhile
-    constexpr int XV = NT;  // float4 per lane: 16 * NT pixels x 4 channel quads / 64 lanes
     const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
     long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
     if (leaf0 >= B) return;
-    float4 xv[XV];
-    {
-        const int np0 = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX;
-        const float4 *xl4 = (const float4 *)(x + (size_t)leaf0 * PIX * 16);
-#pragma unroll
-        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np0 * 4 ? xl4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
-    }
-    int abase[NT];
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pdst[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int m = t * 16 + (lane & 15);
-        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * RB_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+        const int m = t * 16 + n, pc = ptab[m < MP ? m : 0];
+        abase[t] = pc - (PW + 1) * RS_STRIDE + 4 * g;  // this lane's pixel of tile t: top-left tap of its 3x3 window, this lane's channel quad
+        pdst[t] = (m < MP ? pc : IMGW * IMG) + 4 * g;    // where the pixel's channel quad is written (rows past the wave's pixels: the dummy pixel)
     }
-    const int c = lane & 15;
-    const float b0 = bias[c], b1 = bias[16 + c], b2 = bias[32 + c], b3 = bias[48 + c];
+    f32x4 bias4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bias4[k] = *(const f32x4 *)(bias + 16 * k + 4 * g);
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 36 * 64 * 4, RS_BUF_FLAGS);
+    const int rowoff = n * 64 + g * 16;  // byte offset of (pixel n, channel quad g) in a tile's 1 KB of [pixel][16] floats
+    auto task_bytes = [&](long long l0) { return (int)(B - l0 < IMGW ? B - l0 : IMGW) * PIX * 64; };
+    f32x4 xv[NT], xs[NT], wq[3];
+    auto load_x = [&](long long l0) {  // request a task's x in accumulator layout, zeros past its end
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * 16), 0, task_bytes(l0), RS_BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xv[t] = rs_load_b(rs, rowoff, t * 1024);
+    };
+    auto stage_x = [&]() {  // xs = x (skip operand of block 0); relu(x) into the padded images
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { xs[t] = xv[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xv[t]); }
+    };
+    load_x(leaf0);
+    wq[0] = rs_load_b(frs, lane * 16, 0); wq[1] = rs_load_b(frs, lane * 16, 1024);
+    stage_x();
+    if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
+#ifdef RS_STAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define RS_T(k) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; }
+#else
+#define RS_T(k)
+#endif
     for (; leaf0 < B; leaf0 += stride_leaves) {
-    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
-    const float *xl = x + (size_t)leaf0 * PIX * 16;
-    float *ol = out + (size_t)leaf0 * PIX * 16, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 16 : nullptr;
+        const int nbytes = task_bytes(leaf0);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf0 * PIX * 16), 0, nbytes, RS_BUF_FLAGS);
+#ifdef RS_STAMP
+        const bool want_relu = false;  // diagnostic build: out_relu receives the stamps instead
+#else
+        const bool want_relu = out_relu != nullptr;
+#endif
+        f32x4 acc[NT];
+        wave_sync();
+        RS_T(1)
+        rs_conv<NT>(img, frs, 0, 9 * 1024, PW, abase, acc, wq);              // block 0, conv0
+        RS_T(2)
 #pragma unroll
-    for (int k = 0; k < XV; ++k) {  // relu(x) into the padded images, 16 bytes per lane
-        const int e4 = lane + 64 * k;
-        if (e4 < npix * 4) {
-            float *d = img + ptab[e4 >> 2] + 4 * (e4 & 3);
-            d[0] = fmaxf(xv[k].x, 0.f); d[1] = fmaxf(xv[k].y, 0.f); d[2] = fmaxf(xv[k].z, 0.f); d[3] = fmaxf(xv[k].w, 0.f);
+        for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[0]);
+        wave_sync();
+        RS_T(3)
+        rs_conv<NT>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq);      // block 0, conv1 (+ skip x)
+        RS_T(4)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { xs[t] = (acc[t] + bias4[1]) + xs[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // y1, kept as block 1's skip operand
+        wave_sync();
+        RS_T(5)
+        rs_conv<NT>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq);     // block 1, conv0
+        RS_T(6)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[2]);
+        wave_sync();
+        RS_T(7)
+        rs_conv<NT>(img, frs, 27 * 1024, 0, PW, abase, acc, wq);             // block 1, conv1 (+ skip y1)
+        RS_T(8)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = (acc[t] + bias4[3]) + xs[t];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, t * 1024, 0);
         }
-    }
-    if (LOOP && leaf0 + stride_leaves < B) {
-        const long long next0 = leaf0 + stride_leaves;
-        const int np1 = (int)(B - next0 < IMGW ? B - next0 : IMGW) * PIX;
-        const float4 *xn4 = (const float4 *)(x + (size_t)next0 * PIX * 16);
+        if (want_relu) {  // uniform: relu(result) for the next layer's input, a second set of 16-byte stores
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * 16), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
-        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np1 * 4 ? xn4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
-    }
-    f32x4 acc[NT], y1[NT];
-    wave_sync();
-    rs_conv<NT>(img, frag, PW, abase, acc);                       // block 0, conv0
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < npix) img[ptab[m] + c] = fmaxf(acc[t][q] + b0, 0.f); }
-    wave_sync();
-    rs_conv<NT>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int m = t * 16 + (lane >> 4) * 4 + q;
-            float y = 0.f;
-            if (m < npix) { y = (acc[t][q] + b1) + xl[m * 16 + c]; img[ptab[m] + c] = fmaxf(y, 0.f); }
-            y1[t][q] = y;
+            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, t * 1024, 0);
         }
-    wave_sync();
-    rs_conv<NT>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { int m = t * 16 + (lane >> 4) * 4 + q; if (m < npix) img[ptab[m] + c] = fmaxf(acc[t][q] + b2, 0.f); }
-    wave_sync();
-    rs_conv<NT>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int m = t * 16 + (lane >> 4) * 4 + q;
-            if (m < npix) {
-                float y = (acc[t][q] + b3) + y1[t][q];
-                ol[m * 16 + c] = y;
-                if (orl) orl[m * 16 + c] = fmaxf(y, 0.f);
-            }
+        RS_T(9)
+        // the image is free (the last convolution has read it): stage the next task, request the one after
+        if (leaf0 + stride_leaves < B) {
+            stage_x();
+            if (leaf0 + 2 * stride_leaves < B) load_x(leaf0 + 2 * stride_leaves);
         }
-    if (!LOOP) break;
-    wave_sync();
+        RS_T(0)
     }
+#undef RS_T
+#ifdef RS_STAMP  // diagnostic build: per-phase shader-clock totals of all waves, added into the first 80 bytes of `out_relu`
+    if (lane == 0 && out_relu)
+        for (int k = 0; k < 10; ++k) atomicAdd((unsigned long long *)out_relu + k, st_acc[k]);
+#endif
 }
 
 // The same for a 32-channel stage on small images (5x5 at the 20x20 board): M = the pixels of IMGW consecutive leaves (75 of
@@ -2848,28 +2894,20 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
         return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: bad argument (images of at most 128 pixels)");
     if (B == 0) return RP_OK;
     const int PIX = H * W;
-    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * RB_STRIDE * sizeof(float);
-    // leaves per wave: as many as fit 8 pixel tiles (accumulators + the kept skip operand in registers; 13 tiles = two 10x10 leaves
-    // need all 256 VGPRs and measured 246 us against 233 us per 10 923 leaves) and two workgroups per CU
+    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * RS_STRIDE * sizeof(float);
+    // leaves per wave: as many as fit 8 pixel tiles (accumulators + the kept skip operand in registers) and two workgroups per CU
     int imgw = std::max(1, (16 * 8) / PIX);
-    while (imgw > 1 && 4 * imgw * img_bytes + 1024 > 78 * 1024) --imgw;
+    while (imgw > 1 && 4 * (imgw * img_bytes + RS_STRIDE * sizeof(float)) + 1024 > 78 * 1024) --imgw;
     const int nt = (imgw * PIX + 15) / 16;
-    const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * imgw * img_bytes;
+    const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * (imgw * img_bytes + RS_STRIDE * sizeof(float));
     const long long tasks = (B + imgw - 1) / imgw;
-    // the persistent form (next task's x prefetched, as in k_convpool32) spills ~400 VGPRs here -- the kept skip operand and 28
-    // accumulators leave no room -- so it stays an experiment switch
-    static const bool allow_loop = getenv("RP_STAGE16_LOOP") != nullptr;
-    const bool persistent = allow_loop && tasks >= 4 * 2048;
-    const dim3 grid((unsigned)(persistent ? 2 * 256 : (tasks + 3) / 4)), block(256);
+    static const int stage_wgs = getenv("RP_STAGE16_WGS") ? atoi(getenv("RP_STAGE16_WGS")) : 2;  // resident workgroups per CU (registers: 2 waves per SIMD)
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)stage_wgs, (160 * 1024) / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
-        if (persistent) {                                                                                                                           \
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_resstage16<NT_, true>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
-        } else {                                                                                                                                    \
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_resstage16<NT_, false>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
-        }                                                                                                                                           \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL((k_resstage16<NT_>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
         break;
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)

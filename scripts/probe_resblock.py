@@ -14,7 +14,7 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.time() - t) / n * 1e6
 
-for B in (2731, 4096, 10923):
+for B in (10923, 30000, 32768):
     x = torch.randn(B, 16, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
     w0 = torch.randn(16, 16, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last) * 0.1
     w1 = torch.randn(16, 16, 3, 3, device="cuda").contiguous(memory_format=torch.channels_last) * 0.1
