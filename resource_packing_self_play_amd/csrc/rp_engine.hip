@@ -2079,249 +2079,286 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
 #endif
 }
 
-// The same for a 32-channel stage on small images (5x5 at the 20x20 board): M = the pixels of IMGW consecutive leaves (75 of
-// 80 rows at 3 x 25), N = 2 tiles of 16 output channels, K = 9 taps x 32 channels = 72 k-steps.  The B operand no longer
-// fits in registers (144 fragments per convolution), so it streams from L2 -- one 16-byte load per lane per two k-steps
-// ([36][64] float4 = {s even: n-tile 0, 1; s odd: n-tile 0, 1}), prefetched two loads ahead of the 20 MFMAs that consume it.
-// Pixel stride 33 floats keeps the per-k-step A reads (16 pixels x 2 channels per half-wave) on distinct banks.
-#define R32_STRIDE 33
-// fragment order of a [32][Cin][3][3] weight (KS = Cin / 4 k-steps per tap): s = k-step (tap = s / KS, ci = 4 * (s % KS) + (lane >> 4)),
-// co = 16 * nt + (lane & 15); fragq[s / 2][lane] = {s even: n-tile 0, 1; s odd: n-tile 0, 1}
-__global__ void k_pack_conv32(const float *w, float *fragq, int Cin) {
-    const int KS = Cin / 4;
+// The same recipe for the 32-channel stages on small images (5x5 and 3x3 at the 20x20 board): transposed product -- A = weights, two
+// M tiles of 16 output channels, B = the 16 pixels of a tile -- so a lane's accumulators are channel quads 4 * mt + g of ONE pixel
+// (two 16-byte pieces of the channels-last image), skip operands stay in registers, x / the result move as 16-byte loads / stores.
+// M = the pixels of IMGW consecutive leaves (75 of 80 rows at 3 x 25), K = 9 taps x Cin channels.  Within a tap a lane group g
+// multiplies input channels Cin/4 * g + 4 h + j (k-step (h, j), h < Cin / 16): four consecutive channels per half h, one
+// ds_read_b128.  Fragments: frag[tap][h][mt][lane][j] = W[co = 16 mt + (lane & 15)][ci = Cin/4 * (lane >> 4) + 4 h + j][tap], 16 bytes
+// per lane and (tap, h, mt), streamed from L2 through a buffer resource two half-taps ahead of their MFMAs.  Pixel operands are
+// re-requested IN PLACE half a tap (16 * NT / HQ MFMAs) ahead.  The images have no padding floats (LDS: two workgroups per CU): pixel
+// stride = Cin floats, a pixel's channel quad Q sits at slot Q ^ swz(pixel) with swz(p) = 3 (p >> 1) & (Cin / 4 - 1) -- without it
+// sixteen pixels of a tile fall on two bank groups (16.8 LDS cycles per 16-byte read in the model of MI355X_MICROARCH.md, 9.8 with).
+__global__ void k_pack_conv32(const float *w, float *frag, int Cin) {
+    const int HQ = Cin / 16;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * KS * 64 * 2) return;
-    int e = i & 3, l = (i >> 2) & 63, s2 = i >> 8;
-    int s = 2 * s2 + (e >> 1), nt = e & 1;
-    int co = 16 * nt + (l & 15), ci = 4 * (s % KS) + (l >> 4), tap = s / KS;
-    fragq[i] = w[(co * Cin + ci) * 9 + tap];
+    if (i >= 9 * Cin * 32) return;
+    const int j = i & 3, l = (i >> 2) & 63, mt = (i >> 8) & 1, h = (i >> 9) % HQ, tap = (i >> 9) / HQ;
+    const int co = 16 * mt + (l & 15), ci = (Cin / 4) * (l >> 4) + 4 * h + j;
+    frag[i] = w[(co * Cin + ci) * 9 + tap];
 }
-// One 3x3 convolution Cin = 4 * KS -> 32 channels over NT pixel tiles; image pixel stride 4 * KS + 1 floats.
-template <int NT, int KS>
-__device__ __forceinline__ void r32_conv(const float *img, const float4 *__restrict__ fragq, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2]) {
-    constexpr int NS = 9 * KS, STRIDE = 4 * KS + 1;
-    const int lane = lane_id();
-    float4 bq[3];
-    bq[0] = fragq[lane]; bq[1] = fragq[64 + lane];
-    float a_cur[NT], a_nxt[NT];
+template <int CIN> __device__ __forceinline__ int r32_swz(int p) { return (3 * (p >> 1)) & (CIN / 4 - 1); }
+// One 3x3 convolution CIN -> 32 over NT pixel tiles on the swizzled image.  abase[t]: pixel index (not an offset) of the top-left
+// tap of tile t's pixel of this lane; wq: fragments of half-taps (0, 1) on entry, of the NEXT convolution's (byte offset fnext) on exit.
+template <int NT, int CIN>
+__device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
+                                         f32x4 (&wq)[3][2]) {
+    constexpr int HQ = CIN / 16, NH = 9 * HQ;  // half-taps per tap, per convolution
+    const int voff = lane_id() * 16, g = lane_id() >> 4;
+    int z = 0; asm volatile("" : "+v"(z));  // opaque zero: the 9 * NT * HQ swizzled addresses of a convolution must not be hoisted out of the task loop
+    auto a_read = [&](int t, int tap, int h) {
+        const int dr = tap / 3, dx = tap - 3 * dr;
+        const int p = abase[t] + z + dr * PW + dx;
+        return *(const f32x4 *)(img + p * CIN + 4 * ((HQ * g + h) ^ r32_swz<CIN>(p)));
+    };
+    f32x4 a[NT][HQ];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; a_cur[t] = img[abase[t]]; }
+    for (int t = 0; t < NT; ++t) {
+        acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s2 = 0; s2 < NS / 2; ++s2) {
-        if (s2 + 2 < NS / 2) bq[(s2 + 2) % 3] = fragq[(s2 + 2) * 64 + lane];
+        for (int h = 0; h < HQ; ++h) a[t][h] = a_read(t, 0, h);
+    }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int s = 2 * s2 + j;
-            if (s + 1 < NS) {
-                const int tap = (s + 1) / KS, dr = tap / 3, dx = tap - 3 * dr;
-                const int off = (dr * PW + dx) * STRIDE + 4 * ((s + 1) % KS);
+    for (int s = 0; s < NH; ++s) {  // half-tap s = tap * HQ + h
+        const int tap = s / HQ, h = s % HQ;
+        {
+            const int s2 = s + 2, off = s2 < NH ? fbase + s2 * 2048 : fnext + (s2 - NH) * 2048;
+            wq[s2 % 3][0] = rs_load_b(frs, voff, off); wq[s2 % 3][1] = rs_load_b(frs, voff, off + 1024);
+        }
+        const f32x4 w0 = wq[s % 3][0], w1 = wq[s % 3][1];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a_nxt[t] = img[abase[t] + off];
-            }
-            const float b0 = j ? bq[s2 % 3].z : bq[s2 % 3].x, b1 = j ? bq[s2 % 3].w : bq[s2 % 3].y;
+        for (int j = 0; j < 3; ++j) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b0, acc[t][0], 0, 0, 0);
-                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t], b1, acc[t][1], 0, 0, 0);
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[t][h][j], acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[t][h][j], acc[t][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+        for (int t = 0; t < NT; ++t) {
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[3], a[t][h][3], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[3], a[t][h][3], acc[t][1], 0, 0, 0);
+            if (tap + 1 < 9) a[t][h] = a_read(t, tap + 1, h);  // this half's fragment of the next tap: first used a whole tap from here
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
-// frag = [4][36][64] float4, bias = [4][32] in execution order; IMGW leaves per wave, IMGW * PIX <= 16 * NT.
+// frag = [4][9][2][2][64] float4, bias = [4][32] in execution order; IMGW leaves per wave, IMGW * PIX <= 16 * NT.  Persistent waves.
 template <int NT>
-__global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
+__global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
                                                        const int *__restrict__ nrows_dev) {
+    constexpr int CIN = 32;
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * R32_STRIDE, MP = IMGW * PIX;
-    int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
-    float *img = rb_lds + 16 * NT + (size_t)wv * IMGW * IMG;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX, WAVE_P = IMGW * IMGP + 1;  // pixels per wave incl. the dummy
+    int *ptab = (int *)rb_lds;     // [16 * NT] padded pixel index (within the wave's images) of pixel m of the wave's IMGW leaves
+    float *sbias = rb_lds + 16 * NT;  // [4][32]
+    float *img = sbias + 128 + (size_t)wv * WAVE_P * CIN;
     for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
-        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * R32_STRIDE : 0;
+        ptab[i] = i < MP ? im * IMGP + (r + 1) * PW + c + 1 : 0;
     }
-    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;  // borders (and missing leaves of the last group) stay zero
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) sbias[i] = bias[i];
+    {
+        float4 *z4 = (float4 *)img;
+        for (int i = lane; i < WAVE_P * CIN / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // borders (and missing leaves of the last group) stay zero
+    }
     __syncthreads();
-    const long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
+    const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
+    long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
     if (leaf0 >= B) return;
-    const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
-    const float *xl = x + (size_t)leaf0 * PIX * 32;
-    float *ol = out + (size_t)leaf0 * PIX * 32, *orl = out_relu ? out_relu + (size_t)leaf0 * PIX * 32 : nullptr;
-    for (int e4 = lane; e4 < npix * 8; e4 += 64) {  // relu(x) into the padded images
-        float4 v = ((const float4 *)xl)[e4];
-        float *d = img + ptab[e4 >> 3] + 4 * (e4 & 7);
-        d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
-    }
-    int abase[NT];
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pdst[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int m = t * 16 + (lane & 15);
-        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * R32_STRIDE + (lane >> 4);  // top-left tap of the 3x3 window
+        const int m = t * 16 + n, pc = m < MP ? ptab[m] : IMGW * IMGP;  // rows past the wave's pixels: the dummy pixel
+        abase[t] = ptab[m < MP ? m : 0] - (PW + 1);
+        pdst[t][0] = pc * CIN + 4 * ((g) ^ r32_swz<CIN>(pc));       // channel quad g (channels 4 g ..) and
+        pdst[t][1] = pc * CIN + 4 * ((4 + g) ^ r32_swz<CIN>(pc));   // quad 4 + g (channels 16 + 4 g ..) of this lane's pixel
     }
-    const int c = lane & 15;
-    f32x4 acc[NT][2], y1[NT][2];
-    wave_sync();
-    r32_conv<NT, 8>(img, frag, PW, abase, acc);                       // block 0, conv0
-    {
-        const float ba = bias[c], bb = bias[16 + c];
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 9 * CIN * 32 * 4, RS_BUF_FLAGS);
+    constexpr int CONV_BYTES = 9 * CIN * 32 * 4;
+    const int rowoff = n * 128 + g * 16;  // byte offset of (pixel n, channel quad g) in a tile's 2 KB of [pixel][32] floats; quad 4 + g: + 64
+    auto task_bytes = [&](long long l0) { return (int)(B - l0 < IMGW ? B - l0 : IMGW) * PIX * 128; };
+    f32x4 xv[NT][2], xs[NT][2], wq[3][2];
+    auto load_x = [&](long long l0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * CIN), 0, task_bytes(l0), RS_BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { xv[t][0] = rs_load_b(rs, rowoff, t * 2048); xv[t][1] = rs_load_b(rs, rowoff, t * 2048 + 64); }
+    };
+    auto stage_x = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = t * 16 + (lane >> 4) * 4 + q;
-                if (m < npix) { float *d = img + ptab[m] + c; d[0] = fmaxf(acc[t][0][q] + ba, 0.f); d[16] = fmaxf(acc[t][1][q] + bb, 0.f); }
+            for (int mt = 0; mt < 2; ++mt) { xs[t][mt] = xv[t][mt]; *(f32x4 *)(img + pdst[t][mt]) = rs_relu(xv[t][mt]); }
+    };
+    load_x(leaf0);
+    wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
+    wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+    stage_x();
+    if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
+    for (; leaf0 < B; leaf0 += stride_leaves) {
+        const int nbytes = task_bytes(leaf0);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
+        f32x4 acc[NT][2];
+#define R32_BIAS(k) const f32x4 ba = *(const f32x4 *)(sbias + 32 * (k) + 4 * g), bb = *(const f32x4 *)(sbias + 32 * (k) + 16 + 4 * g)
+        wave_sync();
+        r32_conv<NT, CIN>(img, frs, 0, CONV_BYTES, PW, abase, acc, wq);                     // block 0, conv0
+        {
+            R32_BIAS(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
+        }
+        wave_sync();
+        r32_conv<NT, CIN>(img, frs, CONV_BYTES, 2 * CONV_BYTES, PW, abase, acc, wq);        // block 0, conv1 (+ skip x)
+        {
+            R32_BIAS(1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xs[t][0] = (acc[t][0] + ba) + xs[t][0]; xs[t][1] = (acc[t][1] + bb) + xs[t][1];  // y1, kept as block 1's skip operand
+                *(f32x4 *)(img + pdst[t][0]) = rs_relu(xs[t][0]); *(f32x4 *)(img + pdst[t][1]) = rs_relu(xs[t][1]);
             }
-    }
-    wave_sync();
-    r32_conv<NT, 8>(img, frag + 36 * 64, PW, abase, acc);             // block 0, conv1 (+ skip x)
-    {
-        const float ba = bias[32 + c], bb = bias[48 + c];
+        }
+        wave_sync();
+        r32_conv<NT, CIN>(img, frs, 2 * CONV_BYTES, 3 * CONV_BYTES, PW, abase, acc, wq);    // block 1, conv0
+        {
+            R32_BIAS(2);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
+        }
+        wave_sync();
+        r32_conv<NT, CIN>(img, frs, 3 * CONV_BYTES, 0, PW, abase, acc, wq);                 // block 1, conv1 (+ skip y1)
+        {
+            R32_BIAS(3);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = t * 16 + (lane >> 4) * 4 + q;
-                float ya = 0.f, yb = 0.f;
-                if (m < npix) {
-                    ya = (acc[t][0][q] + ba) + xl[m * 32 + c]; yb = (acc[t][1][q] + bb) + xl[m * 32 + 16 + c];
-                    float *d = img + ptab[m] + c; d[0] = fmaxf(ya, 0.f); d[16] = fmaxf(yb, 0.f);
-                }
-                y1[t][0][q] = ya; y1[t][1][q] = yb;
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = (acc[t][0] + ba) + xs[t][0]; acc[t][1] = (acc[t][1] + bb) + xs[t][1];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, t * 2048, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, t * 2048 + 64, 0);
             }
-    }
-    wave_sync();
-    r32_conv<NT, 8>(img, frag + 2 * 36 * 64, PW, abase, acc);         // block 1, conv0
-    {
-        const float ba = bias[64 + c], bb = bias[80 + c];
+        }
+#undef R32_BIAS
+        if (out_relu != nullptr) {  // uniform: relu(result) for the flatten -> hidden_fc path
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = t * 16 + (lane >> 4) * 4 + q;
-                if (m < npix) { float *d = img + ptab[m] + c; d[0] = fmaxf(acc[t][0][q] + ba, 0.f); d[16] = fmaxf(acc[t][1][q] + bb, 0.f); }
+            for (int t = 0; t < NT; ++t) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, t * 2048, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, t * 2048 + 64, 0);
             }
-    }
-    wave_sync();
-    r32_conv<NT, 8>(img, frag + 3 * 36 * 64, PW, abase, acc);         // block 1, conv1 (+ skip y1)
-    {
-        const float ba = bias[96 + c], bb = bias[112 + c];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = t * 16 + (lane >> 4) * 4 + q;
-                if (m < npix) {
-                    float ya = (acc[t][0][q] + ba) + y1[t][0][q], yb = (acc[t][1][q] + bb) + y1[t][1][q];
-                    ol[m * 32 + c] = ya; ol[m * 32 + 16 + c] = yb;
-                    if (orl) { orl[m * 32 + c] = fmaxf(ya, 0.f); orl[m * 32 + 16 + c] = fmaxf(yb, 0.f); }
-                }
-            }
+        }
+        if (leaf0 + stride_leaves < B) {
+            stage_x();
+            if (leaf0 + 2 * stride_leaves < B) load_x(leaf0 + 2 * stride_leaves);
+        }
     }
 }
 
 // Entry of a 32-channel stage (ConvSequence.conv + max_pool2d(3, 2, 1), BinpackingNNet.py:34,39-40): 3x3 convolution
-// Cin = 4 * KS -> 32 channels over the pixels of IMGW consecutive leaves, bias, then the 3x3 / stride-2 max-pool out of an
-// LDS staging copy of the convolution output that overwrites the (fully consumed) input images.  Output: pooled x, channels-last.
-template <int NT, int KS, bool LOOP>
-__global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float4 *__restrict__ frag, const float *__restrict__ bias,
+// CIN -> 32 channels over the pixels of IMGW consecutive leaves (same transposed MFMA stream as above), bias, then the 3x3 / stride-2
+// max-pool out of an LDS staging copy of the convolution output (rows of 36 floats) that overwrites the (fully consumed) input
+// images.  Output: pooled x, channels-last, 16-byte stores.  Persistent waves; the next task's x is requested before this task's
+// convolution.
+template <int NT, int CIN>
+__global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
                                                        const int *__restrict__ nrows_dev) {
-    constexpr int STRIDE = 4 * KS + 1, CIN = 4 * KS;
+    constexpr int XQ = CIN / 16;  // 16-byte pieces of x per lane and tile
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * STRIDE, MP = IMGW * PIX;
-    int *ptab = (int *)rb_lds;
-    float *img = rb_lds + 16 * NT + ((IMGW * (((S_h + 1) >> 1) * ((S_w + 1) >> 1)) + 3) & ~3) + (size_t)wv * wave_floats;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX;
+    const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
+    int *ptab = (int *)rb_lds;            // [16 * NT] padded pixel index of pixel m
+    int *pool = ptab + 16 * NT;           // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
+    float *img = rb_lds + 16 * NT + ((IMGW * PP + 3) & ~3) + (size_t)wv * wave_floats;
     for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
-        ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * STRIDE : 0;
+        ptab[i] = i < MP ? im * IMGP + (r + 1) * PW + c + 1 : 0;
+    }
+    for (int i = threadIdx.x; i < IMGW * PP; i += blockDim.x) {
+        int im = i / PP, pp = i - im * PP, pr = pp / Wp, px = pp - pr * Wp;
+        pool[i] = (im * PIX + 2 * pr * S_w + 2 * px) | ((pr > 0) << 16) | ((2 * pr + 1 < S_h) << 17) | ((px > 0) << 18) | ((2 * px + 1 < S_w) << 19);
     }
     {
-        const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PPn = Hp * Wp;
-        for (int i = threadIdx.x; i < IMGW * PPn; i += blockDim.x) {
-            int im = i / PPn, pp = i - im * PPn, pr = pp / Wp, px = pp - pr * Wp;
-            ptab[16 * NT + i] = (im * PIX + 2 * pr * S_w + 2 * px) | ((pr > 0) << 16) | ((2 * pr + 1 < S_h) << 17) | ((px > 0) << 18) | ((2 * px + 1 < S_w) << 19);
-        }
+        float4 *z4 = (float4 *)img;
+        for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = lane; i < IMGW * IMG; i += 64) img[i] = 0.f;
     __syncthreads();
-    int abase[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int m = t * 16 + (lane & 15);
-        abase[t] = ptab[m < MP ? m : 0] - (PW + 1) * STRIDE + (lane >> 4);
-    }
-    const int c = lane & 15;
-    const float ba = bias[c], bb = bias[16 + c];
-    const int PP = ((S_h + 1) >> 1) * ((S_w + 1) >> 1);
-    const int *pool = ptab + 16 * NT;  // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
-    const int cq = lane & 7;
-    // persistent waves: tables and zero borders once; the NEXT task's x is requested before this task's convolution and lands in
-    // registers while the matrix cores work
-    constexpr int XV = (NT * 16 * KS + 63) / 64;
     const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
     long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
-    float4 xv[XV];
-    if (leaf0 < B) {
-        const int np0 = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX;
-        const float4 *xl4 = (const float4 *)(x + (size_t)leaf0 * PIX * CIN);
+    if (leaf0 >= B) return;
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pin[NT][XQ], m_row[NT];
 #pragma unroll
-        for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np0 * KS ? xl4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int t = 0; t < NT; ++t) {
+        const int m = t * 16 + n, pc = m < MP ? ptab[m] : IMGW * IMGP;  // rows past the wave's pixels: the dummy pixel (behind the images)
+        abase[t] = ptab[m < MP ? m : 0] - (PW + 1);
+        m_row[t] = m;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * CIN + 4 * ((4 * q + g) ^ r32_swz<CIN>(pc));  // where this lane's q-th 16-byte piece of x goes: channel quad 4 q + g
     }
-    for (; leaf0 < B; leaf0 += stride_leaves) {
-        const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW), npix = nimg * PIX;
-#pragma unroll
-        for (int k = 0; k < XV; ++k) {  // x (no ReLU in front of a stage's first convolution) into the padded images
-            const int e4 = lane + 64 * k;
-            if (e4 < npix * KS) { float *d = img + ptab[e4 / KS] + 4 * (e4 % KS); d[0] = xv[k].x; d[1] = xv[k].y; d[2] = xv[k].z; d[3] = xv[k].w; }
-        }
-        const long long next0 = leaf0 + stride_leaves;
-        if (LOOP && next0 < B) {
-            const int np1 = (int)(B - next0 < IMGW ? B - next0 : IMGW) * PIX;
-            const float4 *xn4 = (const float4 *)(x + (size_t)next0 * PIX * CIN);
-#pragma unroll
-            for (int k = 0; k < XV; ++k) { const int e4 = lane + 64 * k; xv[k] = e4 < np1 * KS ? xn4[e4] : make_float4(0.f, 0.f, 0.f, 0.f); }
-        }
-        f32x4 acc[NT][2];
-        wave_sync();
-        r32_conv<NT, KS>(img, frag, PW, abase, acc);
-        wave_sync();
-        // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 9 * CIN * 32 * 4, RS_BUF_FLAGS);
+    const f32x4 ba = *(const f32x4 *)(bias + 4 * g), bb = *(const f32x4 *)(bias + 16 + 4 * g);
+    const int rowoff = n * (CIN * 4) + g * 16;
+    auto task_bytes = [&](long long l0) { return (int)(B - l0 < IMGW ? B - l0 : IMGW) * PIX * CIN * 4; };
+    f32x4 xv[NT][XQ], wq[3][2];
+    auto load_x = [&](long long l0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * CIN), 0, task_bytes(l0), RS_BUF_FLAGS);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int m = t * 16 + (lane >> 4) * 4 + q;
-                if (m < npix) { float *d = img + m * 36 + c; d[0] = acc[t][0][q] + ba; d[16] = acc[t][1][q] + bb; }
-            }
+            for (int q = 0; q < XQ; ++q) xv[t][q] = rs_load_b(rs, rowoff, t * 16 * CIN * 4 + 64 * q);
+    };
+    const int cq = lane & 7;
+    load_x(leaf0);
+    wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
+    wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+    for (; leaf0 < B; leaf0 += stride_leaves) {
+        const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)  // x (no ReLU in front of a stage's first convolution) into the padded images
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = xv[t][q];
+        if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
+        f32x4 acc[NT][2];
         wave_sync();
-        // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table
+        r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
+        wave_sync();
+        // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows; rows past the
+        // wave's pixels land behind the last real row (inside the wave's region: wave_floats covers 16 * NT rows)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            *(f32x4 *)(img + m_row[t] * 36 + 4 * g) = acc[t][0] + ba;
+            *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
+        }
+        wave_sync();
+        // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table.  Branch-free: a neighbour outside
+        // the image reads the centre again (max with itself), so all nine 16-byte reads of a window are in flight together
         float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
         for (int pq = lane >> 3; pq < nimg * PP; pq += 8) {
             const int info = pool[pq], ctr = info & 0xFFFF;
-            const bool up = info & (1 << 16), down = info & (1 << 17), left = info & (1 << 18), right = info & (1 << 19);
+            const int up = (info >> 16) & 1, down = (info >> 17) & 1, left = (info >> 18) & 1, right = (info >> 19) & 1;
             const float4 *row = (const float4 *)(img + ctr * 36) + cq;
-            float4 m = row[0];
-#define POOL_MAX(ok, off)                                                                                       \
-            if (ok) { const float4 v = row[(off) * 9]; m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w); }
-            POOL_MAX(left, -1) POOL_MAX(right, 1)
-            POOL_MAX(up, -S_w) POOL_MAX(up && left, -S_w - 1) POOL_MAX(up && right, -S_w + 1)
-            POOL_MAX(down, S_w) POOL_MAX(down && left, S_w - 1) POOL_MAX(down && right, S_w + 1)
-#undef POOL_MAX
+            const int ou = up ? -S_w : 0, od = down ? S_w : 0, ol = left ? -1 : 0, orr = right ? 1 : 0;
+            const float4 v0 = row[0], v1 = row[ol * 9], v2 = row[orr * 9], v3 = row[ou * 9], v4 = row[(ou + ol) * 9], v5 = row[(ou + orr) * 9],
+                         v6 = row[od * 9], v7 = row[(od + ol) * 9], v8 = row[(od + orr) * 9];
+            float4 m;
+            m.x = fmaxf(fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x)), fmaxf(fmaxf(v4.x, v5.x), fmaxf(fmaxf(v6.x, v7.x), v8.x)));
+            m.y = fmaxf(fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y)), fmaxf(fmaxf(v4.y, v5.y), fmaxf(fmaxf(v6.y, v7.y), v8.y)));
+            m.z = fmaxf(fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3.z)), fmaxf(fmaxf(v4.z, v5.z), fmaxf(fmaxf(v6.z, v7.z), v8.z)));
+            m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)), fmaxf(fmaxf(v4.w, v5.w), fmaxf(fmaxf(v6.w, v7.w), v8.w)));
             o4[pq * 8 + cq] = m;
         }
-        if (!LOOP) break;  // one task per wave: no back edge, nothing kept alive across tasks
         wave_sync();
-        if (next0 < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
+        if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
             float4 *z4 = (float4 *)img;
-            for (int i = lane; i < (IMGW * IMG + 3) / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -2920,7 +2957,7 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
 
 extern "C" int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev, int32_t Cin) {
     if (!ctx || !w_dev || !frag_dev || (Cin != 16 && Cin != 32)) return fail(ctx, RP_ERR_ARG, "rp_nn_pack_conv32: bad argument (Cin 16 or 32)");
-    const int n = 9 * (Cin / 4) * 64 * 2;
+    const int n = 9 * Cin * 32;
     hipLaunchKernelGGL(k_pack_conv32, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, w_dev, frag_dev, (int)Cin);
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
@@ -2931,42 +2968,39 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     if (!ctx || !x_dev || !frag_dev || !bias_dev || !out_dev || B < 0 || H < 1 || W < 1 || (Cin != 16 && Cin != 32) || H * W > (Cin == 16 ? 112 : 80))
         return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: bad argument (Cin 16: <= 112 pixels, Cin 32: <= 80 pixels)");
     if (B == 0) return RP_OK;
-    const int PIX = H * W, stride = Cin + 1, max_tiles = Cin == 16 ? 7 : 5;
-    const size_t img_floats = (size_t)(H + 2) * (W + 2) * stride;
+    const int PIX = H * W, max_tiles = Cin == 16 ? 7 : 5;
+    const size_t img_pixels = (size_t)(H + 2) * (W + 2);
     int imgw = (16 * max_tiles) / PIX;
     const int PPn = ((H + 1) / 2) * ((W + 1) / 2);
-    auto wave_floats = [&](int k) { return (std::max<size_t>(k * img_floats, (size_t)k * PIX * 36) + 3) & ~(size_t)3; };
+    // a wave's region holds its padded input images + the dummy pixel, later the staging copy of 16 * nt rows of 36 floats
+    auto wave_floats = [&](int k) { return (std::max<size_t>((k * img_pixels + 1) * Cin, (size_t)16 * ((k * PIX + 15) / 16) * 36) + 3) & ~(size_t)3; };
     auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + (((size_t)k * PPn + 3) & ~(size_t)3) + 4 * wave_floats(k)) * sizeof(float); };
-    while (imgw > 1 && lds_bytes(imgw) > 80 * 1024) --imgw;  // two workgroups per CU
+    while (imgw > 1 && lds_bytes(imgw) > 78 * 1024) --imgw;  // two workgroups per CU
     const int nt = (imgw * PIX + 15) / 16;
     const size_t wf = wave_floats(imgw), lds = lds_bytes(imgw);
     if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: %dx%d image does not fit LDS", H, W);
     const long long tasks = (B + imgw - 1) / imgw;
-    // persistent waves (two workgroups per CU, next task's input prefetched) once a wave has several tasks; below that one task per
-    // wave balances better (3 641 three-leaf tasks on 2 048 waves would take two rounds)
-    const bool persistent = Cin == 16 && tasks >= 4 * 2048;  // (the 32-channel form keeps 10 + 10 accumulators and 40 prefetch registers: slower as a loop)
-    const dim3 grid((unsigned)(persistent ? 2 * 256 : (tasks + 3) / 4)), block(256);
-#define CP_LAUNCH(NT_, KS_, LOOP_)                                                                                                                   \
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);  // persistent waves
+#define CP_LAUNCH(NT_, CIN_)                                                                                                                         \
     {                                                                                                                                                \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, KS_, LOOP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_convpool32<NT_, KS_, LOOP_>), grid, block, lds, ctx->stream, x_dev, (const float4 *)frag_dev, bias_dev, out_dev, (long long)B, (int)H, \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((k_convpool32<NT_, CIN_>), grid, block, lds, ctx->stream, x_dev, frag_dev, bias_dev, out_dev, (long long)B, (int)H,        \
                            (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                                 \
     }
-#define CP_LAUNCH16(NT_) { if (persistent) CP_LAUNCH(NT_, 4, true) else CP_LAUNCH(NT_, 4, false) }
     if (Cin == 16) {
         switch (nt) {
-            case 1: CP_LAUNCH16(1) break; case 2: CP_LAUNCH16(2) break; case 3: CP_LAUNCH16(3) break; case 4: CP_LAUNCH16(4) break;
-            case 5: CP_LAUNCH16(5) break; case 6: CP_LAUNCH16(6) break; case 7: CP_LAUNCH16(7) break;
+            case 1: CP_LAUNCH(1, 16) break; case 2: CP_LAUNCH(2, 16) break; case 3: CP_LAUNCH(3, 16) break; case 4: CP_LAUNCH(4, 16) break;
+            case 5: CP_LAUNCH(5, 16) break; case 6: CP_LAUNCH(6, 16) break; case 7: CP_LAUNCH(7, 16) break;
             default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
         }
     } else {
         switch (nt) {
-            case 1: CP_LAUNCH(1, 8, false) break; case 2: CP_LAUNCH(2, 8, false) break; case 3: CP_LAUNCH(3, 8, false) break; case 4: CP_LAUNCH(4, 8, false) break;
-            case 5: CP_LAUNCH(5, 8, false) break;
+            case 1: CP_LAUNCH(1, 32) break; case 2: CP_LAUNCH(2, 32) break; case 3: CP_LAUNCH(3, 32) break; case 4: CP_LAUNCH(4, 32) break;
+            case 5: CP_LAUNCH(5, 32) break;
             default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
         }
     }
-#undef CP_LAUNCH16
 #undef CP_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return RP_OK;
@@ -2978,18 +3012,20 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
         return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: bad argument (images of at most 80 pixels)");
     if (B == 0) return RP_OK;
     const int PIX = H * W;
-    const size_t img_bytes = (size_t)(H + 2) * (W + 2) * R32_STRIDE * sizeof(float);
-    int imgw = 80 / PIX;                                              // leaves per wave: at most 5 pixel tiles of 16
-    while (imgw > 1 && 4 * imgw * img_bytes + 320 > 78 * 1024) --imgw;  // two workgroups per CU
+    const size_t img_pixels = (size_t)(H + 2) * (W + 2);
+    auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + 128 + 4 * (k * img_pixels + 1) * 32) * sizeof(float); };
+    int imgw = 80 / PIX;                                   // leaves per wave: at most 5 pixel tiles of 16
+    while (imgw > 1 && lds_bytes(imgw) > 78 * 1024) --imgw;  // two workgroups per CU
     const int nt = (imgw * PIX + 15) / 16;
-    const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * imgw * img_bytes;
+    const size_t lds = lds_bytes(imgw);
     if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: %dx%d image does not fit LDS", H, W);
     const long long tasks = (B + imgw - 1) / imgw;
-    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);  // persistent waves
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage32<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(k_resstage32<NT_>, grid, block, lds, ctx->stream, x_dev, (const float4 *)frag4_dev, bias4_dev, out_dev, out_relu_dev,    \
+        hipLaunchKernelGGL(k_resstage32<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev,                    \
                            (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev);                                                                   \
         break;
     switch (nt) {
