@@ -41,12 +41,13 @@ import numpy as np  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward, default concurrent games per GPU
-    "c1": (10, 10, 8, 25, 2.18e6, 4096),
-    "c2": (10, 10, 8, 100, 2.18e6, 4096),
-    "c3": (20, 20, 32, 400, 10.01e6, 32768),
-    "c4": (20, 20, 32, 100, 10.01e6, 32768),
-    "c5": (50, 50, 128, 800, 133.4e6, 256),
+CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward, default concurrent games per GPU (sized to HBM),
+    # legal-move arena = node arena x this (measured peaks with level reclaim: 1.3 MB per slot at c3, 85 MB at c5)
+    "c1": (10, 10, 8, 25, 2.18e6, 4096, 24),
+    "c2": (10, 10, 8, 100, 2.18e6, 4096, 24),
+    "c3": (20, 20, 32, 400, 10.01e6, 32768, 24),
+    "c4": (20, 20, 32, 100, 10.01e6, 32768, 24),
+    "c5": (50, 50, 128, 800, 133.4e6, 1024, 160),  # 175 MB per slot: 1 024 games = 179 GB of the 288 GB
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
@@ -356,7 +357,7 @@ def parse_args(argv=None):
     ap.add_argument("--games", type=int, default=0, help="concurrent game slots per GPU (default: the configuration's, 32 768 for c3)")
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
-    ap.add_argument("--edge-factor", type=int, default=24, help="legal-move arena = node arena x this (6 B per entry)")
+    ap.add_argument("--edge-factor", type=int, default=0, help="legal-move arena = node arena x this (6 B per entry; default: the configuration's)")
     ap.add_argument("--vis-factor", type=float, default=1.5, help="visited-edge arena = node arena x this (26 B per entry)")
     ap.add_argument("--no-reclaim", action="store_true", help="keep dead levels' arena chunks (needs ~5x the arena)")
     ap.add_argument("--groups", type=int, default=1, help="slot groups per GPU, each with its own stream and graph; 3 co-schedules the groups' kernels "
@@ -374,6 +375,8 @@ def parse_args(argv=None):
     ap.add_argument("--warm-waves", type=int, default=96, help="waves of the short warm-up pass before the first pool")
     ap.add_argument("--event-every", type=int, default=16, help="take per-phase HIP-event timings every n-th wave")
     ap.add_argument("--profile-waves", type=int, default=0, help="profiling aid: stop after this many waves per group and print no metric")
+    ap.add_argument("--waves", type=int, default=0, help="bounded run for configurations whose pool takes many minutes (c5: ~100 k waves): play this many waves of "
+                    "one pool and report expansions/s and simulations/s of that window (no episodes/s: no episode ends inside it)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (ranks, process group, collectives, JSON line) without the GPU work")
     ap.add_argument("--cpu-worker", default=None)
     ap.add_argument("--cpu-episodes", type=int, default=1)
@@ -390,7 +393,8 @@ def main(argv=None):
         sys.exit(spawn_ranks(a.gpus, argv))
 
     t_start = float(os.environ.get("RP_BENCH_T0", T_PROCESS_START))
-    W, H, N, sims, flops_leaf, games_default = CONFIGS[a.config]
+    W, H, N, sims, flops_leaf, games_default, edge_factor_default = CONFIGS[a.config]
+    a.edge_factor = a.edge_factor or edge_factor_default
     sims = a.sims or sims
     games = a.games or games_default
     rank = int(os.environ.get("RANK", "0"))
@@ -442,8 +446,11 @@ def main(argv=None):
     pool = a.pool or games
     node_cap = sims * (N + 1) + 2
     edge_cap, vis_cap = node_cap * a.edge_factor, int(node_cap * a.vis_factor)
-    if sims <= 100 or N <= 16:  # small configurations: one open chunk per reachable level dominates the arena, not the entry count
-        edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * 4096), max(vis_cap, (min(sims, N) + 3) * 1024)
+    # every reachable level keeps one partly filled chunk open (level arenas): small or very deep configurations
+    # are bounded by chunks per level, not by the entry count.  Chunk sizes as rp_create picks them: a chunk holds the largest run.
+    pow2 = lambda v: 1 << max(0, int(v - 1).bit_length())
+    pchunk, vchunk = max(4096, pow2(W * N)), max(1024, pow2(W * N))
+    edge_cap, vis_cap = max(edge_cap, (min(sims, N) + 3) * pchunk), max(vis_cap, (min(sims, N) + 3) * vchunk)
     sp = BatchedSelfPlay(game, nnet, args, games=games, move_rule=_lib.MOVE_SAMPLE, seed=7 + rank, node_cap=node_cap,
                          edge_cap=edge_cap, use_graph=not a.no_graph, groups=a.groups, step_cap=a.step_cap, use_stem=not a.no_stem, fuse_elementwise=not a.no_fuse, dense_small_convs=not a.no_dense,
                          reclaim=not a.no_reclaim, vis_cap=vis_cap, compact_rows=not a.no_compact, channels_last=not a.nchw, resblock_kernel=not a.no_resblock)
@@ -482,6 +489,12 @@ def main(argv=None):
                 waves += 1
             if max_waves and waves >= max_waves:
                 torch.cuda.synchronize(dev)
+                for ev, _, _ in pending:
+                    phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+                    phase_n += 1
+                for name, e0, e1 in kev:
+                    kernel_ms.setdefault(name, []).append(e0.elapsed_time(e1))
+                del kev[:]
                 return waves, 0.0, 0.0
             if sp.active() == 0:
                 break
@@ -505,6 +518,31 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if a.waves > 0:  # bounded window of one pool (c5): steady-state expansion rate, not an episodes/s figure
+        play_pool(0, False, max_waves=min(64, a.waves))
+        sp.counters(reset=True)
+        barrier()
+        t0 = time.time()
+        wv, _, _ = play_pool(0, True, max_waves=a.waves)
+        barrier()
+        dt = allreduce([time.time() - t0], dist.ReduceOp.MAX)[0]
+        c = sp.counters()
+        tot_v = allreduce([float(c[k]) for k in _lib.COUNTER_NAMES], dist.ReduceOp.SUM)
+        if rank == 0:
+            tot = dict(zip(_lib.COUNTER_NAMES, tot_v))
+            print(json.dumps({"metric": "MCTS node expansions/sec (bounded window of one pool)", "value": tot["expansions"] / dt, "unit": "expansions/s",
+                              "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f64 PUCT / f32 Q + CNN, u%d bit-board" % (64 if W > 32 else 32), "data": "synthetic",
+                              "config": {"workload": "%s: %dx%d bin, %d items, %d MCTS sims/move, %d concurrent games per GPU, first %d waves of a pool"
+                                                     % (a.config, W, H, N, sims, games, a.waves)},
+                              "simulations_per_s": tot["simulations"] / dt, "waves": wv, "ms_per_wave": dt / wv * 1e3,
+                              "leaves_per_wave": tot["expansions"] / wv, "valid_per_leaf": tot["sum_valid_leaf"] / max(tot["expansions"], 1),
+                              "path_edges_per_sim": tot["path_edges"] / max(tot["simulations"], 1),
+                              "phase_ms_per_launch": dict(zip(("search", "leaf_stem", "evaluator", "commit"), (phase_ms / max(phase_n, 1)).tolist())),
+                              "device_bytes": sp.device_bytes, "arena_peak_per_slot": sp.arena_peak()}), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     # short warm-up pass: the first waves of a pool (every slot waits for the evaluator: the heaviest waves) through the captured
     # graph and through the event-timed eager path, then the pool is abandoned (rp_begin_pool restarts every slot)
     if a.warm_waves > 0 and not a.profile_waves:

@@ -25,6 +25,8 @@ class MCTS:
         self._wh = None
         self._area = None
         self._buf = None
+        self._generation = 0    # bumped by every search: the dict views below are rebuilt at most once per generation
+        self._dict_cache = None
 
     # ---- engine plumbing ---------------------------------------------------------------------
     def _engine_for(self, rows, remaining, wh, total_area, rewards):
@@ -59,6 +61,7 @@ class MCTS:
     def _run(self, canonicalBoard, totalArea, rewardsList, sims):
         rows, remaining, wh = st.pack_state(canonicalBoard, self._wh)
         eng = self._engine_for(rows, remaining, wh, totalArea, rewardsList)
+        self._generation += 1
         eng.set_sims(sims)
         while eng.search_step() > 0:
             self._evaluate_pending(eng)
@@ -97,6 +100,14 @@ class MCTS:
         return self.game.stringRepresentation(s)
 
     def _dicts(self):
+        """All six dicts from ONE dump of the device tree, cached until the next search (`len(m.Ns)` then `len(m.Es)` is one dump)."""
+        if self._dict_cache is not None and self._dict_cache[0] == self._generation:
+            return self._dict_cache[1]
+        out = self._build_dicts()
+        self._dict_cache = (self._generation, out)
+        return out
+
+    def _build_dicts(self):
         out = {k: {} for k in ("Qsa", "Nsa", "Ns", "Ps", "Es", "Vs")}
         d = self._tree()
         if d is None:
@@ -130,3 +141,4 @@ class MCTS:
         if self._eng is not None:
             self._eng.close()
             self._eng = None
+        self._dict_cache = None

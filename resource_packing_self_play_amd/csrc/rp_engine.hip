@@ -211,64 +211,108 @@ template <typename row_t> __device__ __forceinline__ row_t window(int j, int w, 
 // ------------------------------------------------------------------------------------------------
 // game rules on the register-resident board
 // ------------------------------------------------------------------------------------------------
-// Bin.get_moves_for_square + Bin.get_adjacency for ONE (item, column) per lane
-// (BinPackingLogic.py:80-93 and :47-78).  Must be called by all 64 lanes (it shuffles).
-//   legal  <=>  sum(board[:, j:j+w]) <= w*H - w*h                       (:89, a CELL count)
-//          and  (j == 0  or  board[t, j-1] > 0)                          (:63-70)
-//               with t = first row whose window is empty, H-1 if none   (:66-68 for/break fall-through)
-template <typename row_t>
-__device__ __forceinline__ bool move_is_legal(row_t myrow, int H, int W, int j, int w, int h) {
-    const row_t M = window<row_t>(j, w, W);
-    int occupied = 0, t = -1;
-    for (int r = 0; r < H; ++r) {
-        row_t x = RowOps<row_t>::at(myrow, r) & M;
-        occupied += RowOps<row_t>::popc(x);
-        if (t < 0 && x == 0) t = r;
-    }
-    if (t < 0) t = H - 1;
-    row_t trow = __shfl(myrow, t);
-    bool adjacent = (j == 0) || ((trow >> (j > 0 ? j - 1 : 0)) & 1);
-    return (occupied <= w * H - w * h) && adjacent;
-}
-
 struct ValidSink {  // where gen_valid_moves puts its result
     u16 *act;       // compact legal-move list (or null)
     u8 *mask;       // dense 0/1 mask of A bytes (or null)
     int cap;        // list entries available
+    u64 *vm;        // LDS scratch of the wave: [128] per-item column masks
 };
+#define VM_WORDS 128
 
-// BinPackingGame.getValidMoves (BinPackingGame.py:78-92): lanes stride the action space a = item*W + j,
-// legal moves are compacted in ascending action order with ballot + prefix popcount.
-// Returns the number of legal moves, or -1 if they do not fit sink.cap.
+// BinPackingGame.getValidMoves (BinPackingGame.py:78-92 -> BinPackingLogic.py:80-93 and :47-78) for one state per wave.
+// Whether (item i, column j) is legal depends on the item's SIZE only, and the two conditions separate:
+//   adjacency  (:63-70)  depends on the width w:   j == 0 or cell (t, j - 1) occupied, t = first row whose window [j, j + w) is
+//                         empty (H - 1 if none).  Lane r holds E_w(r) = columns whose window is empty in row r (E_1 = ~row,
+//                         E_w = E_(w-1) & (E_1 >> (w - 1)): two instructions per width for all rows at once); an exclusive prefix-OR
+//                         over the lanes leaves in each lane the columns whose FIRST empty row it is, one AND with (row << 1) tests
+//                         the left neighbour, an OR-reduction gives the width's adjacency mask -- ~30 instructions per width that
+//                         an unplaced item actually has, whatever W and H;
+//   area       (:89)     depends on (w, h):   cells occupied in columns j .. j + w - 1  <=  w (H - h).  Lane c counts column c
+//                         once per state, an inclusive prefix sum turns a window's count into one subtraction per width, and an
+//                         item's mask is one compare + ballot against its threshold.
+// The per-item masks (W bits) go to LDS; then lanes = items: popcounts, a prefix sum for the offsets, and every lane writes its
+// item's actions i * W + j in ascending order.  The previous form tested every (item, column) pair against all H rows:
+// ~5 H instructions per 64 actions, 1 100 per node at 20x20/32 and 25 000 at 50x50/128.
+// Returns the number of legal moves, or -1 if they do not fit sink.cap.  Must be called by all 64 lanes.
 template <typename row_t>
 __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u64 rem1, const ValidSink &sink) {
-    const int lane = lane_id();
-    int nv = 0;
-    for (int base = 0; base < p.A; base += 64) {
-        int a = base + lane;
-        bool act = a < p.A;
-        int i = act ? (int)(((u32)a * p.magicW) >> 20) : 0;
-        int j = a - i * p.W;
-        bool unplaced = ((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull) != 0;  // plane sum != 0 (:86)
-        act = act && unplaced;
-        int w = 1, h = 1;
-        if (act) { w = wh[2 * i]; h = wh[2 * i + 1]; }
-        act = act && (j <= p.W - w);  // for j in range(W - w + 1) (BinPackingLogic.py:87)
-        if (__ballot(act) == 0ull) {
-            if (sink.mask && a < p.A) sink.mask[a] = 0;
-            continue;
-        }
-        if (!act) { j = 0; w = 1; h = 1; }
-        bool ok = move_is_legal<row_t>(myrow, p.H, p.W, j, w, h) && act;
-        u64 m = __ballot(ok);
-        int cnt = __popcll(m);
-        if (sink.mask && a < p.A) sink.mask[a] = ok ? 1 : 0;
-        if (sink.act) {
-            if (nv + cnt > sink.cap) return -1;
-            if (ok) sink.act[nv + __popcll(m & lanes_below())] = (u16)a;
-        }
-        nv += cnt;
+    const int lane = lane_id(), W = p.W, H = p.H, N = p.N;
+    const row_t full = (row_t)full_mask(W);
+    int w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;
+    const bool un_lo = lane < N && ((rem0 >> lane) & 1ull), un_hi = lane + 64 < N && ((rem1 >> lane) & 1ull);  // plane sum != 0 (BinPackingGame.py:86)
+    if (lane < N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
+    if (lane + 64 < N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+    sink.vm[lane] = 0ull;
+    if (N > 64) sink.vm[64 + lane] = 0ull;
+    // occupied cells per column (lane c <-> column c), inclusive prefix sum I and its left neighbour
+    int I = 0;
+    for (int r = 0; r < H; ++r) {
+        const row_t rr = RowOps<row_t>::at(myrow, r);
+        I += lane < W ? (int)((rr >> lane) & 1) : 0;
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(I, o); if (lane >= o) I += v; }
+    int Im1 = __shfl_up(I, 1);
+    if (lane == 0) Im1 = 0;
+    const row_t E1 = lane < H ? (row_t)(~myrow & full) : (row_t)0, left = (row_t)(myrow << 1);  // bit j of `left`: cell (r, j - 1) occupied
+    row_t E = E1;
+    for (int w = 1; w <= W; ++w) {
+        if (w > 1) E = E & (row_t)(E1 >> (w - 1));  // bit j: the window [j, j + w) of this lane's row is empty (and fits: E1 has no bits >= W)
+        const u64 im0 = __ballot(un_lo && w_lo == w), im1 = N > 64 ? __ballot(un_hi && w_hi == w) : 0ull;
+        if ((im0 | im1) == 0ull) continue;  // no unplaced item of this width
+        row_t X = E;  // inclusive prefix-OR over the rows
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const row_t v = __shfl_up(X, o); if (lane >= o) X |= v; }
+        row_t Xex = __shfl_up(X, 1);
+        if (lane == 0) Xex = 0;
+        const row_t anyrow = RowOps<row_t>::at(X, 63);        // columns with an empty window in SOME row
+        row_t G = (row_t)(E & ~Xex) & left;                   // first empty row of the column is this one, and its left neighbour is occupied
+        if (lane == H - 1) G |= (row_t)(~anyrow & full) & left;  // no empty row: the for / break falls through with t = H - 1 (:66-68)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) G |= __shfl_xor(G, o);
+        const u64 adj = (u64)((G | (row_t)1) & (row_t)full_mask(W - w + 1));  // j == 0 is always adjacent; for j in range(W - w + 1) (:87)
+        const int S = __shfl(I, (lane + w - 1) & 63) - Im1;  // cells occupied in columns lane .. lane + w - 1
+        for (u64 m = im0; m; m &= m - 1) {
+            const int i = __ffsll((long long)m) - 1, h = __builtin_amdgcn_readlane(h_lo, i);
+            const u64 v = __ballot(S <= w * H - w * h) & adj;
+            if (lane == 0) sink.vm[i] = v;
+        }
+        for (u64 m = im1; m; m &= m - 1) {
+            const int i = __ffsll((long long)m) - 1, h = __builtin_amdgcn_readlane(h_hi, i);
+            const u64 v = __ballot(S <= w * H - w * h) & adj;
+            if (lane == 0) sink.vm[64 + i] = v;
+        }
+    }
+    wave_sync();
+    // lanes = items: counts, offsets, actions in ascending order
+    u64 m_lo = sink.vm[lane], m_hi = N > 64 ? sink.vm[64 + lane] : 0ull;
+    int inc_lo = __popcll(m_lo), inc_hi = __popcll(m_hi);
+    const int c_lo = inc_lo, c_hi = inc_hi;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(inc_lo, o), b = __shfl_up(inc_hi, o);
+        if (lane >= o) { inc_lo += a; inc_hi += b; }
+    }
+    const int tot_lo = __builtin_amdgcn_readlane(inc_lo, 63), nv = tot_lo + __builtin_amdgcn_readlane(inc_hi, 63);
+    if (sink.mask)
+        for (int a = lane; a < p.A; a += 64) sink.mask[a] = 0;
+    if (sink.act && nv > sink.cap) return -1;
+    wave_sync();
+    int pos = inc_lo - c_lo;
+    for (; m_lo; m_lo &= m_lo - 1) {
+        const int a = lane * W + (__ffsll((long long)m_lo) - 1);
+        if (sink.act) sink.act[pos] = (u16)a;
+        if (sink.mask) sink.mask[a] = 1;
+        ++pos;
+    }
+    pos = tot_lo + inc_hi - c_hi;
+    for (; m_hi; m_hi &= m_hi - 1) {
+        const int a = (64 + lane) * W + (__ffsll((long long)m_hi) - 1);
+        if (sink.act) sink.act[pos] = (u16)a;
+        if (sink.mask) sink.mask[a] = 1;
+        ++pos;
+    }
+    wave_sync();
     return nv;
 }
 
@@ -412,8 +456,9 @@ template <typename row_t> struct Tree {
     u32 n_nodes;
     u64 c_probes, c_keybytes, c_nodes;
     u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
+    u64 *vm;       // this wave's LDS scratch for gen_valid_moves ([VM_WORDS]), with `stage`
 
-    __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr) : p(p_), g(g_), stage(stage_) {
+    __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr, u64 *vm_ = nullptr) : p(p_), g(g_), stage(stage_), vm(vm_) {
         hdr = p.hdr + (size_t)g * p.node_cap;
         key = p.key + (size_t)g * p.node_cap * p.KW;
         size_t eb = (size_t)g * p.edge_cap, vb = (size_t)g * p.vis_cap;
@@ -512,7 +557,7 @@ template <typename row_t> struct Tree {
         // has (a run reserved for the worst case -- one move per unplaced item and column -- opened a fresh chunk per node on
         // large boards: 460 of 6 400 entries used at 50x50/128).
         ValidSink sink;
-        sink.act = stage; sink.mask = nullptr; sink.cap = p.A;
+        sink.act = stage; sink.mask = nullptr; sink.cap = p.A; sink.vm = vm;
         const int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
         wave_sync();
         u32 room, off = 0;
@@ -858,7 +903,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
     if (g >= p.G) return;
     int phase = p.phase[g];
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
     u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
@@ -942,7 +988,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
     if (g >= p.G) return;
     if (p.phase[g] != RP_PHASE_MOVE_READY) return;
     extern __shared__ u16 s_stage[];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
     u32 c[CNT_N];
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
@@ -1343,7 +1390,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
         wave_sync();
     }
     extern __shared__ u16 s_stage[];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
     if (clear_tree) { t.reset_arenas(); wave_sync(); }
     row_t myrow; u64 rem0, rem1;
     if (rows) {
@@ -1373,7 +1421,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     int phase = p.phase[g];
     if (phase != RP_PHASE_MOVE_READY && phase != RP_PHASE_RUNNING) return;
     extern __shared__ u16 s_stage[];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = p.root[g];
@@ -1404,7 +1453,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (g >= p.G) return;
     extern __shared__ u16 s_stage[];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = NONE32;
@@ -1564,8 +1614,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long
     if (b >= B) return;
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0;
+    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6];
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     if (nvalid && lane_id() == 0) nvalid[b] = nv;
 }
@@ -1603,8 +1654,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long 
     if (b >= B) return;
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0;
+    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6];
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     double r = 0.0;
     int e = 0;
@@ -2568,8 +2620,8 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         delete ctx;
         return fail(nullptr, RP_ERR_DEVICE, "rp_create: device initialisation failed");
     }
-    if (STAGE_BYTES(d) + 8192 > 64 * 1024) {  // A > ~7 000: static + staging LDS pass the default 64 KB limit
-        const int lim = (int)(STAGE_BYTES(d) + 8192);
+    if (STAGE_BYTES(d) + 9 * 1024 > 64 * 1024) {  // A > ~6 900: static (8 KB) + staging LDS pass the default 64 KB limit
+        const int lim = (int)(STAGE_BYTES(d) + 9 * 1024);
         if (ctx->row64) {
             (void)hipFuncSetAttribute((const void *)k_search<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
             (void)hipFuncSetAttribute((const void *)k_moves<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);

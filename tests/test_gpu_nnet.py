@@ -249,7 +249,10 @@ def test_mcts_class_matches_oracle_with_cnn_outputs_fed_back():
         a = int(np.argmax(probs))
         board, planes = game.getNextState(board, a, planes)
     assert len(mcts.Ns) > 0 and len(mcts.Es) >= len(mcts.Ns)
+    views = mcts._dicts()
+    assert mcts._dicts() is views and mcts.Qsa is views["Qsa"]  # one tree dump serves all six dicts until the next search
     v = mcts.search(game.getBinItem(board, planes), W * H, [0.9, 0.95])
+    assert mcts._dicts() is not views
     assert isinstance(v, (int, np.ndarray))
     mcts.close(); m.close()
 
