@@ -1242,7 +1242,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
     float unit[STEM_C];
 #pragma unroll
     for (int o = 0; o < STEM_C; ++o) { bias[o] = p.stemBias[o]; unit[o] = p.stemScale[o]; }
-    for (long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); b < limit; b += (long long)gridDim.x * WAVES_PER_BLOCK) {
+    // T_LDS: a wave per leaf.  Table in L2 (N > 40: 204 KB at N = 128): a WORKGROUP per leaf, its four waves take every fourth pass --
+    // a 50x50 leaf is 25 passes x 128 items of dependent L2 reads (0.9 ms per leaf for one wave, whatever the batch size)
+    const int wv_ = threadIdx.x >> 6;
+    for (long long b = T_LDS ? (long long)blockIdx.x * WAVES_PER_BLOCK + wv_ : (long long)blockIdx.x; b < limit;
+         b += T_LDS ? (long long)gridDim.x * WAVES_PER_BLOCK : (long long)gridDim.x) {
         const int g = p.rows_identity ? (int)b : p.eval_slot[b];
         if (p.phase[g] != RP_PHASE_WAIT_EVAL) continue;
         Tree<row_t> t(p, g);
@@ -1259,6 +1263,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
         const int rpp = 64 / p.Wp;
         const int lr = lane / p.Wp, px = lane - lr * p.Wp;
         for (int base = 0, pass = 0; base + (pass ? 1 : 0) < p.Hp; base += rpp - 1, ++pass) {
+            if (!T_LDS && (pass & (WAVES_PER_BLOCK - 1)) != wv_) continue;
             const int pr = base + lr;
             const bool live = lr < rpp && pr < p.Hp;
             const int ra = 2 * pr, xa = 2 * px;
@@ -2892,7 +2897,8 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     if (rows == 0) return RP_OK;
     const size_t t_bytes = (size_t)d.N * 25 * STEM_C * sizeof(int);
     const bool t_lds = t_bytes <= 64 * 1024;
-    const int grid = (int)std::min<long long>(grid_for(rows), t_lds ? 256 * 3 : 1 << 20);  // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32)
+    // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32), a wave per leaf; L2 form: a workgroup per leaf
+    const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? 256 * 3 : 1 << 20);
     if (ctx->row64) {
         if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
         else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
