@@ -483,13 +483,13 @@ def main(argv=None):
                     for g in sp.groups[1:]:
                         sp.step_group(g)
                     sp.steps += 1
-                    pending.append((ev, pi, v))
+                    pending.append(ev)  # (pi, v) live on the group's stream: the caching allocator may reuse them once the commit is enqueued
                 else:
                     sp.step()
                 waves += 1
             if max_waves and waves >= max_waves:
                 torch.cuda.synchronize(dev)
-                for ev, _, _ in pending:
+                for ev in pending:
                     phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
                     phase_n += 1
                 for name, e0, e1 in kev:
@@ -503,7 +503,7 @@ def main(argv=None):
                 print("profile run: stopped after %d waves per group" % waves, file=sys.stderr)
                 sys.exit(0)
         torch.cuda.synchronize(dev)
-        for ev, _, _ in pending:
+        for ev in pending:
             phase_ms += [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
             phase_n += 1
         for name, e0, e1 in kev:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 2
+#define RP_ABI_VERSION 3  /* 3: fragment orders of rp_nn_pack_conv16 / 32 changed, rp_examples_meta added */
 
 typedef enum rp_status {
     RP_OK = 0,
@@ -190,20 +190,24 @@ int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev /* relu(out), 
  * Channels-last tensors: call the first two with (B*H*W, C, 1), the pool with channels_last = 1. */
 /* Fused residual block of the 16-channel stage on the FP32 matrix cores, channels-last [B][H][W][16]:
  *   out = x + conv1(relu(conv0(relu(x)) + b0)) + b1 ; out_relu = relu(out)   (BinpackingNNet.py:21-27)
- * rp_nn_pack_conv16 reorders a contiguous [16][16][3][3] weight into MFMA B-fragment order ([36][64] floats). */
+ * rp_nn_pack_conv16 reorders a contiguous [16][16][3][3] weight into the kernels' fragment order, [9 taps][64 lanes][4]:
+ * frag[tap][lane][j] = W[co = lane & 15][ci = 4 * (lane >> 4) + j][tap] (a lane's four k-steps of a tap are four consecutive input
+ * channels: one 16-byte load). */
 int rp_nn_pack_conv16(rp_ctx *ctx, const float *w_dev, float *frag_dev);
 /* Value head in one pass: out[b] = tanh(dot(z[b, :K], w) + bias[0])  (value_fc + tanh, BinpackingNNet.py:70,81); K a multiple of 4. */
 int rp_nn_value_head(rp_ctx *ctx, const float *z_dev, const float *w_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t K);
 int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *frag0_dev, const float *bias0_dev, const float *frag1_dev, const float *bias1_dev,
                      float *out_dev, float *out_relu_dev /* may be NULL */, int64_t B, int32_t H, int32_t W);
 /* Both residual blocks of a 16-channel stage (ConvSequence.res_block0 then res_block1, BinpackingNNet.py:41-46) in one launch for
- * images of at most 128 pixels: frag4 = [4][36][64] fragments and bias4 = [4][16] in execution order (block 0 conv0, conv1,
- * block 1 conv0, conv1).  out_relu_dev may be NULL. */
+ * images of at most 128 pixels: frag4 = four rp_nn_pack_conv16 fragments (16-byte aligned) and bias4 = [4][16] in execution order
+ * (block 0 conv0, conv1, block 1 conv0, conv1).  out_relu_dev may be NULL.  The product is taken transposed (weights x pixels), so
+ * x, the skip operands and the result move as 16-byte pieces of the channels-last tensors; persistent waves. */
 int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                      int32_t H, int32_t W);
 /* The same for a 32-channel stage on images of at most 80 pixels (5x5 at the 20x20 board).  rp_nn_pack_conv32 reorders a
- * contiguous [32][Cin][3][3] weight (Cin 16 or 32) into the kernels' streaming B-fragment order ([9 * Cin / 8][64][4] floats);
- * frag4 = four of those (Cin 32), bias4 = [4][32], in execution order. */
+ * contiguous [32][Cin][3][3] weight (Cin 16 or 32) into [9 taps][Cin / 16 halves][2 M tiles][64 lanes][4]:
+ * frag[tap][h][mt][lane][j] = W[co = 16 mt + (lane & 15)][ci = Cin / 4 * (lane >> 4) + 4 h + j][tap];
+ * frag4 = four of those (Cin 32, 16-byte aligned), bias4 = [4][32], in execution order. */
 int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_dev, int32_t Cin);
 int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                      int32_t H, int32_t W);

@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librp_engine.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MOVE_EXTERNAL, MOVE_ARGMAX_FIRST, MOVE_SAMPLE = 0, 1, 2
 PHASE_IDLE, PHASE_RUNNING, PHASE_WAIT_EVAL, PHASE_MOVE_READY, PHASE_EPISODE_DONE, PHASE_FAILED = range(6)
