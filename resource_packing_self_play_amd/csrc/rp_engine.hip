@@ -167,6 +167,8 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ void wave_sync() {
     // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
     // memory operations across the point and makes earlier stores visible to the other lanes.
+    // (A wavefront-scope fence -- no s_waitcnt vmcnt(0) -- passes every parity test and measures the same: k_search is bound by
+    // instruction issue, 3 waves x ~16 k issue cycles in a 65 k-cycle wave lifetime, not by these drains.)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
@@ -216,6 +218,7 @@ struct ValidSink {  // where gen_valid_moves puts its result
     u8 *mask;       // dense 0/1 mask of A bytes (or null)
     int cap;        // list entries available
     u64 *vm;        // LDS scratch of the wave: [128] per-item column masks
+    int have_sizes, w_lo, h_lo, w_hi, h_hi;  // item sizes of lanes' items (i, 64 + i) when the caller loaded them already
 };
 #define VM_WORDS 128
 
@@ -238,10 +241,13 @@ template <typename row_t>
 __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u64 rem1, const ValidSink &sink) {
     const int lane = lane_id(), W = p.W, H = p.H, N = p.N;
     const row_t full = (row_t)full_mask(W);
-    int w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;
+    int w_lo = sink.w_lo, h_lo = sink.h_lo, w_hi = sink.w_hi, h_hi = sink.h_hi;
     const bool un_lo = lane < N && ((rem0 >> lane) & 1ull), un_hi = lane + 64 < N && ((rem1 >> lane) & 1ull);  // plane sum != 0 (BinPackingGame.py:86)
-    if (lane < N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
-    if (lane + 64 < N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+    if (!sink.have_sizes) {
+        w_lo = h_lo = w_hi = h_hi = 0;
+        if (lane < N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
+        if (lane + 64 < N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+    }
     sink.vm[lane] = 0ull;
     if (N > 64) sink.vm[64 + lane] = 0ull;
     // occupied cells per column (lane c <-> column c), inclusive prefix sum I and its left neighbour
@@ -431,11 +437,16 @@ __device__ void arena_free_level(const Arena &a, int d) {
         a.head[d] = 0xFFFFu; a.cur[d] = 0xFFFFu; a.used[d] = 0;
     }
 }
-__device__ void arena_reset(const Arena &a, int levels) {
+// A never-used chunk is taken only while the stack of recycled ones is empty, so the high-water mark of chunks in use is tf[1]
+// itself: it is folded into `peak` when an episode's arenas are reset (and read live by k_reduce_peaks), not after every launch.
+__device__ void arena_reset(const Arena &a, int levels, u32 *peak) {
     for (int d = lane_id(); d < levels; d += 64) { a.cur[d] = 0xFFFFu; a.head[d] = 0xFFFFu; a.used[d] = 0; }
-    if (lane_id() == 0) { a.tf[0] = 0; a.tf[1] = 0; }
+    if (lane_id() == 0) {
+        const u32 hw = a.tf[1];
+        if (hw > *peak) *peak = hw;
+        a.tf[0] = 0; a.tf[1] = 0;
+    }
 }
-__device__ u32 arena_in_use(const Arena &a) { return a.tf[1] - a.tf[0]; }
 
 // ------------------------------------------------------------------------------------------------
 // slot-local tree
@@ -457,6 +468,7 @@ template <typename row_t> struct Tree {
     u64 c_probes, c_keybytes, c_nodes;
     u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
     u64 *vm;       // this wave's LDS scratch for gen_valid_moves ([VM_WORDS]), with `stage`
+    int have_sizes = 0, w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;  // the slot's item sizes in lanes (load_sizes), constant over an episode
 
     __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr, u64 *vm_ = nullptr) : p(p_), g(g_), stage(stage_), vm(vm_) {
         hdr = p.hdr + (size_t)g * p.node_cap;
@@ -477,14 +489,19 @@ template <typename row_t> struct Tree {
         c_probes = c_keybytes = c_nodes = 0;
     }
     __device__ void store_sizes() {
-        if (lane_id() == 0) {
-            p.n_nodes[g] = n_nodes;
-            u32 a = arena_in_use(pa), b = arena_in_use(va), *pk = p.peak_chunks + (size_t)g * 2;
-            if (a > pk[0]) pk[0] = a;
-            if (b > pk[1]) pk[1] = b;
-        }
+        if (lane_id() == 0) p.n_nodes[g] = n_nodes;
     }
-    __device__ void reset_arenas() { arena_reset(pa, p.N + 1); arena_reset(va, p.N + 1); }
+    // requested at kernel start, next to the slot's other state, instead of as a dependent read inside every node creation
+    __device__ void load_sizes() {
+        const int lane = lane_id();
+        if (lane < p.N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
+        if (lane + 64 < p.N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+        have_sizes = 1;
+    }
+    __device__ void reset_arenas() {
+        arena_reset(pa, p.N + 1, p.peak_chunks + (size_t)g * 2);
+        arena_reset(va, p.N + 1, p.peak_chunks + (size_t)g * 2 + 1);
+    }
     static __device__ __forceinline__ int level_of(int N, u64 rem0, u64 rem1) { return N - __popcll(rem0) - __popcll(rem1); }
 
     // key of a node -> lane-resident rows + uniform remaining words
@@ -558,6 +575,7 @@ template <typename row_t> struct Tree {
         // large boards: 460 of 6 400 entries used at 50x50/128).
         ValidSink sink;
         sink.act = stage; sink.mask = nullptr; sink.cap = p.A; sink.vm = vm;
+        sink.have_sizes = have_sizes; sink.w_lo = w_lo; sink.h_lo = h_lo; sink.w_hi = w_hi; sink.h_hi = h_hi;
         const int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
         wave_sync();
         u32 room, off = 0;
@@ -631,13 +649,14 @@ template <typename row_t> struct Tree {
         wave_sync();
         return true;
     }
-    // appends the visited entry of legal move k (Nsa = 0 until the backup reaches it); returns its index or NONE32
-    __device__ u32 append_visited(u32 node, NodeHdr &hd, u32 k) {
+    // appends the visited entry of legal move k (Nsa = 0 until the backup reaches it); returns its index or NONE32.  pi = the move's
+    // float32 prior (pPi[hd.prior_off + k], which the caller has in a register already)
+    __device__ u32 append_visited(u32 node, NodeHdr &hd, u32 k, float pi) {
         if (hd.vis_n == hd.vis_cap && !grow_visited(node, hd)) return NONE32;
         const u32 e = hd.vis_off + hd.vis_n;
         if (lane_id() == 0) {
             vIdx[e] = (u16)k; vN[e] = 0u; vQ[e] = 0.0; vChild[e] = NONE32;
-            vP[e] = prior_of(pPi[hd.prior_off + k], hd.norm, (hd.flags & HF_FALLBACK) != 0);
+            vP[e] = prior_of(pi, hd.norm, (hd.flags & HF_FALLBACK) != 0);
             hdr[node].vis_n = (u16)(hd.vis_n + 1);
         }
         hd.vis_n++;
@@ -646,13 +665,21 @@ template <typename row_t> struct Tree {
     // PUCT argmax (MCTS_bpp.py:106-121), float64, strict '>' in ascending action order == maximum with the lowest legal-
     // move index.  Visited edges come from the node's block (Q + cpuct*P*sqrt(Ns)/(1+Nsa)), all others from the prior run
     // (cpuct*P*sqrt(Ns+EPS)); an LDS bit mask tells the two apart.  Returns the visited-entry index of the chosen edge
-    // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.
-    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out, u32 &child_out) {
+    // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.  act_out: the edge's action when it
+    // was chosen among the unvisited moves (the only edges whose child still has to be resolved), else -1.
+    // Memory round trips: the prior run's first 64 (action, pi) pairs are requested BEFORE the visited pass, and the winner's pi
+    // and action ride through the argmax shuffles -- append_visited and resolve_child then need no dependent re-read.
+    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out, u32 &child_out, int &act_out) {
         const int lane = lane_id();
         const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
         const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
         double best_u = -INFINITY;
         u32 best_k = NONE32, best_e = NONE32, best_c = NONE32;
+        float best_pi = 0.f;
+        int best_a = -1;
+        float pi0 = 0.f;
+        int act0 = 0;
+        if ((u32)lane < hd.n_valid) { pi0 = pPi[hd.prior_off + lane]; act0 = pAct[hd.prior_off + lane]; }
         const bool any_visited = hd.vis_n != 0;
         if (any_visited) {
             const u32 words = ((u32)hd.n_valid + 31u) >> 5;
@@ -664,27 +691,34 @@ template <typename row_t> struct Tree {
                 u32 nn = vN[e] & NSA_MASK, ch = vChild[e];  // the child link rides along: no extra round trip after the argmax
                 double cp = p.cpuct * vP[e];
                 double u = nn ? vQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
-                if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; }
+                if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; best_a = -1; }
             }
             wave_sync();
         }
         const bool fb = (hd.flags & HF_FALLBACK) != 0;
         for (u32 k = lane; k < hd.n_valid; k += 64) {
             if (any_visited && ((vmask[k >> 5] >> (k & 31)) & 1u)) continue;
-            double u = (p.cpuct * prior_of(pPi[hd.prior_off + k], hd.norm, fb)) * s_new;
-            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = NONE32; best_c = NONE32; }
+            const float pik = k < 64u ? pi0 : pPi[hd.prior_off + k];
+            double u = (p.cpuct * prior_of(pik, hd.norm, fb)) * s_new;
+            if (u > best_u || (u == best_u && k < best_k)) {
+                best_u = u; best_k = k; best_e = NONE32; best_c = NONE32; best_pi = pik;
+                best_a = k < 64u ? act0 : (int)pAct[hd.prior_off + k];
+            }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             double ou = __shfl_xor(best_u, o);
             u32 ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o), oc = __shfl_xor(best_c, o);
-            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; best_c = oc; }
+            float opi = __shfl_xor(best_pi, o);
+            int oa = __shfl_xor(best_a, o);
+            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; best_c = oc; best_pi = opi; best_a = oa; }
         }
         if (any_visited) wave_sync();  // the mask is reused by the next selection
         k_out = best_k;
         child_out = best_c;
+        act_out = best_a;
         if (best_k == NONE32) return NONE32;
-        if (best_e == NONE32) best_e = append_visited(node, hd, best_k);
+        if (best_e == NONE32) best_e = append_visited(node, hd, best_k, best_pi);
         return best_e;
     }
     // visited entry of legal move k, or NONE32
@@ -709,12 +743,15 @@ template <typename row_t> struct Tree {
     }
 };
 
+// Per-slot event counts: lane k adds counter k -- one coalesced read-modify-write instead of lane 0 walking the sixteen counters one
+// dependent memory round trip after the other (that walk was a fifth of k_search's wait cycles).
 template <typename T> __device__ void add_counters(const DP &p, int g, const T *c) {
-    if (lane_id() == 0) {
-        u64 *dst = p.slot_cnt + (size_t)g * CNT_N;
-        for (int k = 0; k < CNT_N; ++k)
-            if (c[k]) dst[k] += (u64)c[k];
-    }
+    const int lane = lane_id();
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < CNT_N; ++k)
+        if (lane == k) mine = (u64)c[k];
+    if (lane < CNT_N && mine) p.slot_cnt[(size_t)g * CNT_N + lane] += mine;
 }
 
 __device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(mix64(seed) ^ episode) ^ move); }
@@ -736,7 +773,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
         }
         if (ksel != NONE32 && (hd.flags & HF_EXPANDED)) {
             chosen = t.find_visited(hd, ksel);
-            if (chosen == NONE32) chosen = t.append_visited(root, hd, ksel);  // a legal move the search never tried
+            if (chosen == NONE32) chosen = t.append_visited(root, hd, ksel, t.pPi[hd.prior_off + ksel]);  // a legal move the search never tried
         } else if (ksel != NONE32) {
             free_action = action;
         }
@@ -901,14 +938,16 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
     u32 *vmask = s_vmask[threadIdx.x >> 6];
     const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
     if (g >= p.G) return;
+    // the slot's state is requested in one go (phase, root, simulations done, node count, item sizes): one memory round trip, not five
     int phase = p.phase[g];
-    if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
-    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
-    u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
-    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
+    __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    t.load_sizes();
+    if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
+    u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
+    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     int launched = 0;
     for (;;) {
         // A slot near the end of its game runs many evaluator-free simulations (terminal hits); the cap bounds the
@@ -932,8 +971,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
             }
             if (!(hd.flags & HF_EXPANDED)) { need_eval = true; break; }  // :85 leaf
             u32 ksel, child;
+            int act_sel;
             const u32 vis_before = hd.vis_n;
-            u32 e = t.select_edge(node, hd, vmask, ksel, child);
+            u32 e = t.select_edge(node, hd, vmask, ksel, child, act_sel);
             c[CNT_VIS_NEW] += hd.vis_n - vis_before;
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
             if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
@@ -942,7 +982,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
             c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid; c[CNT_VIS_SEL] += vis_before;
             if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
                 bool was_new;
-                child = t.resolve_child(node, e, t.pAct[hd.prior_off + ksel], &was_new);
+                child = t.resolve_child(node, e, act_sel >= 0 ? act_sel : (int)t.pAct[hd.prior_off + ksel], &was_new);
                 if (child == NONE32) { failed = true; break; }
                 if (!was_new) c[CNT_TRANSPOSE]++;
                 wave_sync();
@@ -1606,7 +1646,10 @@ __global__ void k_reduce_counters(DP p) {  // totals over slots; one workgroup, 
 __global__ void k_reduce_peaks(DP p, u32 *out2) {
     __shared__ u32 m0[256], m1[256];
     u32 a = 0, b = 0;
-    for (int g = threadIdx.x; g < p.G; g += 256) { a = max(a, p.peak_chunks[(size_t)g * 2]); b = max(b, p.peak_chunks[(size_t)g * 2 + 1]); }
+    for (int g = threadIdx.x; g < p.G; g += 256) {  // finished episodes' marks and the running episode's chunks taken so far
+        a = max(a, max(p.peak_chunks[(size_t)g * 2], p.pa_tf[(size_t)g * 2 + 1]));
+        b = max(b, max(p.peak_chunks[(size_t)g * 2 + 1], p.va_tf[(size_t)g * 2 + 1]));
+    }
     m0[threadIdx.x] = a; m1[threadIdx.x] = b;
     __syncthreads();
     if (threadIdx.x == 0) { for (int i = 1; i < 256; ++i) { a = max(a, m0[i]); b = max(b, m1[i]); } out2[0] = a; out2[1] = b; }
@@ -1621,7 +1664,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6];
+    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6]; sink.have_sizes = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     if (nvalid && lane_id() == 0) nvalid[b] = nv;
 }
@@ -1661,7 +1704,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long 
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6];
+    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6]; sink.have_sizes = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     double r = 0.0;
     int e = 0;
