@@ -183,6 +183,27 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Wave-wide scans on the DPP path: one VALU instruction per step (row_shr:1/2/4/8 inside the 16-lane rows, row_bcast:15 and
+// row_bcast:31 across them) instead of a ds_bpermute + select + op per step.  Lanes a step has no source for read 0, the identity of
+// OR and of unsigned ADD, so no per-step predicate is needed.  All 64 lanes must be active.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ u32 dpp_or_zero(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+__device__ __forceinline__ u32 wave_scan_or(u32 v) {  // inclusive, ascending lanes
+    v |= dpp_or_zero<0x111, 0xf>(v); v |= dpp_or_zero<0x112, 0xf>(v); v |= dpp_or_zero<0x114, 0xf>(v); v |= dpp_or_zero<0x118, 0xf>(v);
+    v |= dpp_or_zero<0x142, 0xa>(v); v |= dpp_or_zero<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ u64 wave_scan_or(u64 v) {
+    return ((u64)wave_scan_or((u32)(v >> 32)) << 32) | wave_scan_or((u32)v);
+}
+__device__ __forceinline__ u32 wave_scan_add(u32 v) {  // inclusive, ascending lanes
+    v += dpp_or_zero<0x111, 0xf>(v); v += dpp_or_zero<0x112, 0xf>(v); v += dpp_or_zero<0x114, 0xf>(v); v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v); v += dpp_or_zero<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ u32 wave_shift_up1(u32 v) { return dpp_or_zero<0x138, 0xf>(v); }  // lane l reads lane l - 1 (wave_shr:1), lane 0 reads 0
+__device__ __forceinline__ u64 wave_shift_up1(u64 v) { return ((u64)wave_shift_up1((u32)(v >> 32)) << 32) | wave_shift_up1((u32)v); }
 __device__ __forceinline__ u64 mix64(u64 x) {  // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -256,26 +277,20 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
         const row_t rr = RowOps<row_t>::at(myrow, r);
         I += lane < W ? (int)((rr >> lane) & 1) : 0;
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(I, o); if (lane >= o) I += v; }
-    int Im1 = __shfl_up(I, 1);
-    if (lane == 0) Im1 = 0;
+    I = (int)wave_scan_add((u32)I);
+    const int Im1 = (int)wave_shift_up1((u32)I);
     const row_t E1 = lane < H ? (row_t)(~myrow & full) : (row_t)0, left = (row_t)(myrow << 1);  // bit j of `left`: cell (r, j - 1) occupied
     row_t E = E1;
     for (int w = 1; w <= W; ++w) {
         if (w > 1) E = E & (row_t)(E1 >> (w - 1));  // bit j: the window [j, j + w) of this lane's row is empty (and fits: E1 has no bits >= W)
         const u64 im0 = __ballot(un_lo && w_lo == w), im1 = N > 64 ? __ballot(un_hi && w_hi == w) : 0ull;
         if ((im0 | im1) == 0ull) continue;  // no unplaced item of this width
-        row_t X = E;  // inclusive prefix-OR over the rows
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const row_t v = __shfl_up(X, o); if (lane >= o) X |= v; }
-        row_t Xex = __shfl_up(X, 1);
-        if (lane == 0) Xex = 0;
+        const row_t X = wave_scan_or(E);                      // inclusive prefix-OR over the rows
+        const row_t Xex = wave_shift_up1(X);
         const row_t anyrow = RowOps<row_t>::at(X, 63);        // columns with an empty window in SOME row
         row_t G = (row_t)(E & ~Xex) & left;                   // first empty row of the column is this one, and its left neighbour is occupied
         if (lane == H - 1) G |= (row_t)(~anyrow & full) & left;  // no empty row: the for / break falls through with t = H - 1 (:66-68)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) G |= __shfl_xor(G, o);
+        G = RowOps<row_t>::at(wave_scan_or(G), 63);           // OR over all rows
         const u64 adj = (u64)((G | (row_t)1) & (row_t)full_mask(W - w + 1));  // j == 0 is always adjacent; for j in range(W - w + 1) (:87)
         const int S = __shfl(I, (lane + w - 1) & 63) - Im1;  // cells occupied in columns lane .. lane + w - 1
         for (u64 m = im0; m; m &= m - 1) {
@@ -294,11 +309,8 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
     u64 m_lo = sink.vm[lane], m_hi = N > 64 ? sink.vm[64 + lane] : 0ull;
     int inc_lo = __popcll(m_lo), inc_hi = __popcll(m_hi);
     const int c_lo = inc_lo, c_hi = inc_hi;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int a = __shfl_up(inc_lo, o), b = __shfl_up(inc_hi, o);
-        if (lane >= o) { inc_lo += a; inc_hi += b; }
-    }
+    inc_lo = (int)wave_scan_add((u32)inc_lo);
+    if (N > 64) inc_hi = (int)wave_scan_add((u32)inc_hi);
     const int tot_lo = __builtin_amdgcn_readlane(inc_lo, 63), nv = tot_lo + __builtin_amdgcn_readlane(inc_hi, 63);
     if (sink.mask)
         for (int a = lane; a < p.A; a += 64) sink.mask[a] = 0;
@@ -705,14 +717,23 @@ template <typename row_t> struct Tree {
                 best_a = k < 64u ? act0 : (int)pAct[hd.prior_off + k];
             }
         }
+        // wave argmax on (u, lowest k) only; the winner's payload (entry, child, pi, action) is then read from its lane
+        double win_u = best_u;
+        u32 win_k = best_k;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
-            double ou = __shfl_xor(best_u, o);
-            u32 ok = __shfl_xor(best_k, o), oe = __shfl_xor(best_e, o), oc = __shfl_xor(best_c, o);
-            float opi = __shfl_xor(best_pi, o);
-            int oa = __shfl_xor(best_a, o);
-            if (ou > best_u || (ou == best_u && ok < best_k)) { best_u = ou; best_k = ok; best_e = oe; best_c = oc; best_pi = opi; best_a = oa; }
+            const double ou = __shfl_xor(win_u, o);
+            const u32 ok = __shfl_xor(win_k, o);
+            if (ou > win_u || (ou == win_u && ok < win_k)) { win_u = ou; win_k = ok; }
         }
+        if (win_k != NONE32) {  // uniform; legal-move indices are unique across lanes, so exactly one lane holds the winner
+            const int wl = __ffsll((long long)__ballot(best_k == win_k)) - 1;
+            best_e = (u32)__builtin_amdgcn_readlane((int)best_e, wl);
+            best_c = (u32)__builtin_amdgcn_readlane((int)best_c, wl);
+            best_pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_pi), wl));
+            best_a = __builtin_amdgcn_readlane(best_a, wl);
+        }
+        best_k = win_k;
         if (any_visited) wave_sync();  // the mask is reused by the next selection
         k_out = best_k;
         child_out = best_c;
@@ -1117,21 +1138,26 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id(), wv = threadIdx.x >> 6;
     if (b >= (p.rows_identity ? p.G : *p.eval_count)) return;
     const int g = p.rows_identity ? b : p.eval_slot[b];
-    if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
-    Tree<row_t> t(p, g);
+    // everything that depends on the slot only is requested together (one memory round trip): phase, leaf, path, the value
+    const int phase = p.phase[g];
     const u32 node = p.leaf_node[g];
+    const int depth = p.path_len[g];
+    const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
+    const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
+    u32 e0 = 0, n0 = 0, e1 = 0, n1 = 0;  // path entries of levels lane and 64 + lane (entries past `depth` are stale and unused)
+    if (lane < p.N) { e0 = pe[lane]; n0 = pn[lane]; }
+    if (lane + 64 < p.N) { e1 = pe[lane + 64]; n1 = pn[lane + 64]; }
+    if (phase != RP_PHASE_WAIT_EVAL) return;
+    Tree<row_t> t(p, g);
     NodeHdr hd = t.hdr[node];
+    // backup along the stored path (:130-139) first: its loads travel with the header's
+    if (lane < depth) t.backup_entry(n0, e0, v, RP_KIND_F32);
+    if (lane + 64 < depth) t.backup_entry(n1, e1, v, RP_KIND_F32);
     bool fb;
     double norm = masked_prior(p, pi + (size_t)b * p.A, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
         hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
         t.hdr[node] = hd;
-    }
-    const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
-    const int depth = p.path_len[g];
-    const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
-    for (int d = lane; d < depth; d += 64) t.backup_entry(pn[d], pe[d], v, RP_KIND_F32);
-    if (lane == 0) {
         p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32;
         u64 *cn = p.slot_cnt + (size_t)g * CNT_N;
         cn[CNT_SIMS] += 1; cn[CNT_EXPAND] += 1; cn[CNT_NVALID_LEAF] += hd.n_valid;
