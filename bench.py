@@ -60,9 +60,11 @@ ENGINE_SRC = os.path.join(ROOT, "resource_packing_self_play_amd", "csrc", "rp_en
 # budget planner (pure functions: tests/test_bench_contract.py runs them on the CPU)
 # ---------------------------------------------------------------------------------------------------------------------
 def classify_pools(n_done, steps, warmup):
-    """(warm-up pools, timed pools) among n_done completed pools: timed steps come first, up to `steps`; what ran before
-    them counts as warm-up, at most `warmup`."""
-    warm = min(int(warmup), max(0, n_done - int(steps)))
+    """(warm-up pools, timed pools) among n_done completed pools: the LAST pools are the timed steps, up to `steps`; what
+    ran before them counts as warm-up, at most `warmup`.  When the budget cut the run short the first pool still stays
+    untimed (if a warm-up was asked for and a second pool exists), so a timed step never includes first-touch effects."""
+    floor = 1 if (int(warmup) > 0 and n_done >= 2) else 0
+    warm = min(int(warmup), max(floor, n_done - int(steps)))
     return warm, n_done - warm
 
 
@@ -283,7 +285,12 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
     nn_tflops = rows * (flops_leaf - stem_flops) / (eval_ms * 1e-3) / 1e12 if eval_ms > 0 else 0.0
     kflops = stage_kernel_flops(W, H)
     Hs, Ws = (H + 1) // 2, (W + 1) // 2
-    kbytes = {"k_resstage16 %dx%d" % (Hs, Ws): 2 * 4 * 16 * Hs * Ws}  # x in, result out, per leaf
+    Hs2, Ws2 = (Hs + 1) // 2, (Ws + 1) // 2
+    Hs3, Ws3 = (Hs2 + 1) // 2, (Ws2 + 1) // 2
+    kbytes = {"k_resstage16 %dx%d" % (Hs, Ws): 2 * 4 * 16 * Hs * Ws,  # x in, result out, per leaf
+              "k_resstage32 %dx%d" % (Hs2, Ws2): 2 * 4 * 32 * Hs2 * Ws2, "k_resstage32 %dx%d" % (Hs3, Ws3): 2 * 4 * 32 * Hs3 * Ws3,
+              "k_convpool32 16->32 %dx%d" % (Hs, Ws): 4 * 16 * Hs * Ws + 4 * 32 * Hs2 * Ws2,
+              "k_convpool32 32->32 %dx%d" % (Hs2, Ws2): 4 * 32 * Hs2 * Ws2 + 4 * 32 * Hs3 * Ws3}
     pmc, pmc_note = load_pmc_traffic()
     roof = None
     timed = {k: v for k, v in kernel_ms.items() if k in kflops}
@@ -293,8 +300,12 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
         ach = rows * kflops[kname] / (kms * 1e-3) / 1e12
         traffic = None
         if pmc is not None:
-            rec = pmc.get("kernels", {}).get(kname.split(" ")[0])
-            if rec and rec.get("leaves_per_launch"):  # the PMC passes cover the pool's first waves (every slot waiting): scale per leaf
+            # a kernel with several template instances in a wave (5x5 / 3x3 stages) appears once per instance in the PMC file
+            # ("k_resstage32<5>"): take the instance whose bytes per leaf are nearest this launch's algorithmic bytes
+            base = kname.split(" ")[0]
+            cands = [r for k, r in pmc.get("kernels", {}).items() if (k == base or k.startswith(base + "<")) and r.get("leaves_per_launch")]
+            if cands:  # the PMC passes cover the pool's first waves (every slot waiting): scale per leaf
+                rec = min(cands, key=lambda r: abs(r["hbm_bytes_per_launch"] / r["leaves_per_launch"] - kbytes.get(kname, 0)))
                 traffic = rec["hbm_bytes_per_launch"] / rec["leaves_per_launch"] * rows
         roof = {"kernel": kname + " (FP32 MFMA, own HIP kernel)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": pmc_note, "flops_per_launch": rows * kflops[kname],

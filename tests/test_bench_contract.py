@@ -31,7 +31,8 @@ def test_short_requests_run_exactly_as_asked():
 
 
 def test_timed_steps_take_priority_over_warmup():
-    assert bench.classify_pools(9, 20, 5) == (0, 9)
+    assert bench.classify_pools(9, 20, 5) == (1, 8)  # budget cut: one pool stays untimed
+    assert bench.classify_pools(9, 20, 0) == (0, 9)
     assert bench.classify_pools(22, 20, 5) == (2, 20)
     assert bench.classify_pools(25, 20, 5) == (5, 20)
     assert bench.classify_pools(1, 1, 1) == (0, 1)
