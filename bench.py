@@ -373,7 +373,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-reclaim", action="store_true", help="keep dead levels' arena chunks (needs ~5x the arena)")
     ap.add_argument("--groups", type=int, default=1, help="slot groups per GPU, each with its own stream and graph; 3 co-schedules the groups' kernels "
                     "(+4 %% episodes/s) but then no kernel has the GPU to itself and per-kernel durations stop meaning anything")
-    ap.add_argument("--step-cap", type=int, default=16, help="max simulations a slot runs per wave (bounds the launch tail)")
+    ap.add_argument("--step-cap", type=int, default=4, help="max simulations a slot runs per wave (bounds the launch tail; 3-6 measure the same, 16: -1.6 %)")
     ap.add_argument("--no-stem", action="store_true", help="feed FP32 planes to the full CNN instead of computing conv1 + pool in the engine")
     ap.add_argument("--no-fuse", action="store_true", help="leave bias / ReLU / skip / pool to PyTorch's own element-wise kernels")
     ap.add_argument("--no-dense", action="store_true", help="keep <= 3x3-image convolutions on MIOpen instead of one GEMM each")

@@ -106,7 +106,10 @@ struct DP {  // device view of a context, passed by value to every kernel
     // k_compact builds in slot order when the host asks for the number of waiting leaves
     int rows_identity;
     int *eval_count, *eval_slot;
-    // arenas
+    // arenas: ONE slab per slot (slab_stride bytes apart) holding the slot's ten regions back to back, hottest first -- a wave's
+    // accesses then fall into 2-3 translation fragments instead of ten (UTCL2 was busy 76 % of k_search with one array per
+    // region across all slots); the pointers below are slot 0's regions, slot g's are slab_stride * g bytes further
+    size_t slab_stride;
     NodeHdr *hdr;   // [G][node_cap]
     u32 *key;       // [G][node_cap][KW]
     u16 *pAct;      // [G][edge_cap]  legal moves of every node, ascending action
@@ -164,6 +167,9 @@ __device__ __forceinline__ void set_error(const DP &p, int code) { atomicCAS(p.e
 // wave helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// index of this wave in its workgroup, as a wave-uniform (SGPR) value: everything derived from it -- the slot id, the slot's region
+// pointers -- then lives in scalar registers; derived from threadIdx.x alone the compiler keeps all of it per lane
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ void wave_sync() {
     // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
     // memory operations across the point and makes earlier stores visible to the other lanes.
@@ -460,6 +466,11 @@ __device__ void arena_reset(const Arena &a, int levels, u32 *peak) {
     }
 }
 
+// region pointer of slot g (DP::slab_stride)
+template <typename T> __device__ __host__ __forceinline__ T *slot_region(const DP &p, T *slot0, int g) {
+    return (T *)((u8 *)slot0 + (size_t)g * p.slab_stride);
+}
+
 // ------------------------------------------------------------------------------------------------
 // slot-local tree
 // ------------------------------------------------------------------------------------------------
@@ -483,12 +494,11 @@ template <typename row_t> struct Tree {
     int have_sizes = 0, w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;  // the slot's item sizes in lanes (load_sizes), constant over an episode
 
     __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr, u64 *vm_ = nullptr) : p(p_), g(g_), stage(stage_), vm(vm_) {
-        hdr = p.hdr + (size_t)g * p.node_cap;
-        key = p.key + (size_t)g * p.node_cap * p.KW;
-        size_t eb = (size_t)g * p.edge_cap, vb = (size_t)g * p.vis_cap;
-        pAct = p.pAct + eb; pPi = p.pPi + eb;
-        vIdx = p.vIdx + vb; vN = p.vN + vb; vQ = p.vQ + vb; vP = p.vP + vb; vChild = p.vChild + vb;
-        table = p.table + (size_t)g * p.table_cap;
+        hdr = slot_region(p, p.hdr, g);
+        key = slot_region(p, p.key, g);
+        pAct = slot_region(p, p.pAct, g); pPi = slot_region(p, p.pPi, g);
+        vIdx = slot_region(p, p.vIdx, g); vN = slot_region(p, p.vN, g); vQ = slot_region(p, p.vQ, g); vP = slot_region(p, p.vP, g); vChild = slot_region(p, p.vChild, g);
+        table = slot_region(p, p.table, g);
         wh = p.item_wh + (size_t)g * p.N * 2;
         n_nodes = p.n_nodes[g];
         const size_t lv = (size_t)g * (p.N + 1);
@@ -956,15 +966,15 @@ template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(DP p) {
     __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     extern __shared__ u16 s_stage[];  // [WAVES_PER_BLOCK][A]
-    u32 *vmask = s_vmask[threadIdx.x >> 6];
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    u32 *vmask = s_vmask[wave_in_block()];
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id();
     if (g >= p.G) return;
     // the slot's state is requested in one go (phase, root, simulations done, node count, item sizes): one memory round trip, not five
     int phase = p.phase[g];
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     t.load_sizes();
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
     u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
@@ -1045,12 +1055,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
 // simulation loop does not carry this code's registers.
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (g >= p.G) return;
     if (p.phase[g] != RP_PHASE_MOVE_READY) return;
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     u32 c[CNT_N];
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
@@ -1135,9 +1145,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
     __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
-    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id(), wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id(), wv = wave_in_block();
     if (b >= (p.rows_identity ? p.G : *p.eval_count)) return;
-    const int g = p.rows_identity ? b : p.eval_slot[b];
+    const int g = __builtin_amdgcn_readfirstlane(p.rows_identity ? b : p.eval_slot[b]);
     // everything that depends on the slot only is requested together (one memory round trip): phase, leaf, path, the value
     const int phase = p.phase[g];
     const u32 node = p.leaf_node[g];
@@ -1187,9 +1197,9 @@ __device__ void write_planes(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u
 }
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_planes(DP p, float *planes, long long capacity_rows) {
-    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int b = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= (p.rows_identity ? p.G : *p.eval_count) || b >= capacity_rows) return;
-    const int g = p.rows_identity ? b : p.eval_slot[b];
+    const int g = __builtin_amdgcn_readfirstlane(p.rows_identity ? b : p.eval_slot[b]);
     if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     row_t myrow; u64 rem0, rem1;
@@ -1310,10 +1320,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
     for (int o = 0; o < STEM_C; ++o) { bias[o] = p.stemBias[o]; unit[o] = p.stemScale[o]; }
     // T_LDS: a wave per leaf.  Table in L2 (N > 40: 204 KB at N = 128): a WORKGROUP per leaf, its four waves take every fourth pass --
     // a 50x50 leaf is 25 passes x 128 items of dependent L2 reads (0.9 ms per leaf for one wave, whatever the batch size)
-    const int wv_ = threadIdx.x >> 6;
+    const int wv_ = wave_in_block();
     for (long long b = T_LDS ? (long long)blockIdx.x * WAVES_PER_BLOCK + wv_ : (long long)blockIdx.x; b < limit;
          b += T_LDS ? (long long)gridDim.x * WAVES_PER_BLOCK : (long long)gridDim.x) {
-        const int g = p.rows_identity ? (int)b : p.eval_slot[b];
+        const int g = __builtin_amdgcn_readfirstlane(p.rows_identity ? (int)b : p.eval_slot[b]);
         if (p.phase[g] != RP_PHASE_WAIT_EVAL) continue;
         Tree<row_t> t(p, g);
         row_t myrow; u64 rem0, rem1;
@@ -1422,9 +1432,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
 
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_states(DP p, u64 *rows_out, u8 *rem_out, int *slot_out, int max_rows) {
-    const int b = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    const int b = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id();
     if (b >= *p.eval_count || b >= max_rows) return;
-    const int g = p.eval_slot[b];
+    const int g = __builtin_amdgcn_readfirstlane(p.eval_slot[b]);
     if (p.phase[g] != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     row_t myrow; u64 rem0, rem1;
@@ -1447,11 +1457,11 @@ __device__ void load_host_state(const DP &p, const u64 *rows, const u8 *rem, row
 // given state while keeping the tree (rows != nullptr).
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int first, int count, const u64 *rows, const u8 *rem, int clear_tree) {
-    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    const int k = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id();
     if (k >= count) return;
     const int g = first + k;
     if (clear_tree) {
-        u64 *tab = p.table + (size_t)g * p.table_cap;
+        u64 *tab = slot_region(p, p.table, g);
         for (int s = lane; s < p.table_cap; s += 64) tab[s] = 0ull;
         if (lane == 0) {
             p.n_nodes[g] = 0; p.moves[g] = 0;
@@ -1462,7 +1472,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
     }
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     if (clear_tree) { t.reset_arenas(); wave_sync(); }
     row_t myrow; u64 rem0, rem1;
     if (rows) {
@@ -1486,14 +1496,14 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
 
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int first, int count, const int *action) {
-    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int k = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (k >= count) return;
     const int g = first + k;
     int phase = p.phase[g];
     if (phase != RP_PHASE_MOVE_READY && phase != RP_PHASE_RUNNING) return;
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = p.root[g];
@@ -1505,7 +1515,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
 
 // counts[a] = Nsa[(root, a)] (MCTS_bpp.py:40-41)
 __global__ void k_root_counts(DP p, int first, int count, u32 *out) {
-    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6), lane = lane_id();
+    const int k = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id();
     if (k >= count) return;
     const int g = first + k;
     u32 *o = out + (size_t)k * p.A;
@@ -1513,19 +1523,20 @@ __global__ void k_root_counts(DP p, int first, int count, u32 *out) {
     wave_sync();
     u32 root = p.root[g];
     if (root == NONE32) return;
-    NodeHdr hd = p.hdr[(size_t)g * p.node_cap + root];
-    const u16 *act = p.pAct + (size_t)g * p.edge_cap + hd.prior_off;
-    size_t vb = (size_t)g * p.vis_cap + hd.vis_off;
-    for (u32 j = lane; j < hd.vis_n; j += 64) o[act[p.vIdx[vb + j]]] = p.vN[vb + j] & NSA_MASK;
+    NodeHdr hd = slot_region(p, p.hdr, g)[root];
+    const u16 *act = slot_region(p, p.pAct, g) + hd.prior_off;
+    const u16 *vi = slot_region(p, p.vIdx, g) + hd.vis_off;
+    const u32 *vn = slot_region(p, p.vN, g) + hd.vis_off;
+    for (u32 j = lane; j < hd.vis_n; j += 64) o[act[vi[j]]] = vn[j] & NSA_MASK;
 }
 
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
-    const int g = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (g >= p.G) return;
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)(threadIdx.x >> 6) * p.A, s_vm[threadIdx.x >> 6]);
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     u64 c[CNT_N];
     for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = NONE32;
@@ -1539,7 +1550,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
 // float64 rounded to float32 (MCTS_bpp.py:51-54 then torch.FloatTensor, NNet.py:46), value = ranked outcome.
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, long long first, long long count, float *planes, float *pi, float *value) {
-    const long long k = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const long long k = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (k >= count) return;
     const long long idx = first + k;
     const int lane = lane_id();
@@ -1684,20 +1695,20 @@ __global__ void k_reduce_peaks(DP p, u32 *out2) {
 // ---- stateless rule kernels (one wave per state) ----
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_valid_moves(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, u8 *mask, int *nvalid) {
-    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= B) return;
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6]; sink.have_sizes = 0;
+    sink.act = nullptr; sink.mask = mask + b * p.A; sink.cap = 0; sink.vm = s_vm[wave_in_block()]; sink.have_sizes = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     if (nvalid && lane_id() == 0) nvalid[b] = nv;
 }
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_apply_move(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, const int *action,
                                                                       u64 *rows_out, u8 *rem_out, int *status) {
-    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= B) return;
     const int lane = lane_id();
     row_t myrow; u64 rem0, rem1;
@@ -1724,13 +1735,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_apply_move(DP p, long 
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_game_ended(DP p, long long B, const u64 *rows, const u8 *rem, const u8 *wh, const int *area,
                                                                       const int *max_h, int has_buf, double bl, int *ended, double *reward) {
-    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= B) return;
     row_t myrow; u64 rem0, rem1;
     load_host_state<row_t>(p, rows + b * p.H, rem + b * p.N, myrow, rem0, rem1);
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     ValidSink sink;
-    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0; sink.vm = s_vm[threadIdx.x >> 6]; sink.have_sizes = 0;
+    sink.act = nullptr; sink.mask = nullptr; sink.cap = 0; sink.vm = s_vm[wave_in_block()]; sink.have_sizes = 0;
     int nv = gen_valid_moves<row_t>(p, wh + b * p.N * 2, myrow, rem0, rem1, sink);
     double r = 0.0;
     int e = 0;
@@ -1762,9 +1773,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
     __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
-    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= B) return;
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int lane = lane_id(), wv = wave_in_block();
     u16 *act = act_scratch + b * p.A;
     float *pc = pi_scratch + b * p.A;
     double *o = out + b * p.A;
@@ -1891,7 +1902,7 @@ __global__ void __launch_bounds__(256) k_nn_bias_pool_nhwc4(const float4 *__rest
 __global__ void __launch_bounds__(256) k_nn_value_head(const float4 *__restrict__ z, const float4 *__restrict__ w, const float *__restrict__ bias,
                                                      float *__restrict__ out, long long B, int K4) {
     const int lane = lane_id();
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long b = (long long)blockIdx.x * 4 + wave_in_block();
     if (b >= B) return;
     const float4 *zr = z + b * K4;
     float acc = 0.f;
@@ -1993,7 +2004,7 @@ __device__ __forceinline__ void rb_conv_all(const float *img, const float (&bf)[
 __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float *frag0, const float *bias0, const float *frag1, const float *bias1, float *out,
                                                     float *out_relu, long long B, int S_h, int S_w) {
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int lane = lane_id(), wv = wave_in_block();
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RB_STRIDE;
     int *ptab = (int *)rb_lds;                       // [PIX] padded LDS offset of every pixel's channel 0 (shared by the block)
     float *img0 = rb_lds + ((PIX + 3) & ~3) + (size_t)wv * 2 * IMG, *img1 = img0 + IMG;
@@ -2097,7 +2108,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     // the wave index as a scalar: everything derived from it (task numbers, buffer resources) is then provably wave-uniform; a
     // resource the compiler takes for divergent costs a waterfall loop around every buffer load and store
-    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }  // only the first *nrows_dev rows hold leaves (compact rows)
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RS_STRIDE, MP = IMGW * PIX, WAVE_F = IMGW * IMG + RS_STRIDE;
@@ -2278,7 +2289,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
                                                        const int *__restrict__ nrows_dev) {
     constexpr int CIN = 32;
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX, WAVE_P = IMGW * IMGP + 1;  // pixels per wave incl. the dummy
@@ -2395,7 +2406,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
                                                        const int *__restrict__ nrows_dev) {
     constexpr int XQ = CIN / 16;  // 16-byte pieces of x per lane and tile
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
-    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX;
@@ -2666,10 +2677,21 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
     A_(d.last_outcome, G); A_(d.last_score, G); A_(d.last_v, G); A_(d.last_vkind, G);
     A_(d.eval_count, 1); A_(d.eval_slot, G);
-    A_(d.hdr, G * d.node_cap); A_(d.key, G * d.node_cap * d.KW);
-    A_(d.pAct, G * d.edge_cap); A_(d.pPi, G * d.edge_cap);
-    A_(d.vIdx, G * d.vis_cap); A_(d.vN, G * d.vis_cap); A_(d.vQ, G * d.vis_cap); A_(d.vP, G * d.vis_cap); A_(d.vChild, G * d.vis_cap);
-    A_(d.table, G * d.table_cap);
+    {   // the slot slabs: one allocation, regions 256-byte aligned, hottest first (headers, hash table, visited blocks, keys, legal-move runs)
+        size_t off = 0;
+        auto region = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_hdr = region((size_t)d.node_cap * sizeof(NodeHdr)), o_table = region((size_t)d.table_cap * 8);
+        const size_t o_vIdx = region((size_t)d.vis_cap * 2), o_vN = region((size_t)d.vis_cap * 4), o_vChild = region((size_t)d.vis_cap * 4);
+        const size_t o_vQ = region((size_t)d.vis_cap * 8), o_vP = region((size_t)d.vis_cap * 8);
+        const size_t o_key = region((size_t)d.node_cap * d.KW * 4), o_pAct = region((size_t)d.edge_cap * 2), o_pPi = region((size_t)d.edge_cap * 4);
+        d.slab_stride = off;
+        u8 *slab = nullptr;
+        A_(slab, G * d.slab_stride);
+        d.hdr = (NodeHdr *)(slab + o_hdr); d.table = (u64 *)(slab + o_table);
+        d.vIdx = (u16 *)(slab + o_vIdx); d.vN = (u32 *)(slab + o_vN); d.vChild = (u32 *)(slab + o_vChild);
+        d.vQ = (double *)(slab + o_vQ); d.vP = (double *)(slab + o_vP);
+        d.key = (u32 *)(slab + o_key); d.pAct = (u16 *)(slab + o_pAct); d.pPi = (float *)(slab + o_pPi);
+    }
     A_(d.pa_cur, G * (N + 1)); A_(d.pa_head, G * (N + 1)); A_(d.pa_used, G * (N + 1)); A_(d.pa_next, G * d.n_pchunks); A_(d.pa_stack, G * d.n_pchunks); A_(d.pa_tf, G * 2);
     A_(d.va_cur, G * (N + 1)); A_(d.va_head, G * (N + 1)); A_(d.va_used, G * (N + 1)); A_(d.va_next, G * d.n_vchunks); A_(d.va_stack, G * d.n_vchunks); A_(d.va_tf, G * 2);
     A_(d.peak_chunks, G * 2 + 2);
@@ -3473,16 +3495,15 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
     std::vector<u16> vI(nv);
     std::vector<float> pi(ne);
     std::vector<double> vQ(nv), vP(nv);
-    HIPCHK(ctx, hipMemcpy(hdr.data(), d.hdr + (size_t)slot * d.node_cap, (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(key.data(), d.key + (size_t)slot * d.node_cap * d.KW, (size_t)nn * d.KW * 4, hipMemcpyDeviceToHost));
-    size_t eb = (size_t)slot * d.edge_cap, vb = (size_t)slot * d.vis_cap;
-    HIPCHK(ctx, hipMemcpy(edge_action, d.pAct + eb, (size_t)ne * 2, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(pi.data(), d.pPi + eb, (size_t)ne * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vI.data(), d.vIdx + vb, (size_t)nv * 2, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vN.data(), d.vN + vb, (size_t)nv * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vC.data(), d.vChild + vb, (size_t)nv * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vQ.data(), d.vQ + vb, (size_t)nv * 8, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vP.data(), d.vP + vb, (size_t)nv * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(hdr.data(), slot_region(d, d.hdr, slot), (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(key.data(), slot_region(d, d.key, slot), (size_t)nn * d.KW * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(edge_action, slot_region(d, d.pAct, slot), (size_t)ne * 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(pi.data(), slot_region(d, d.pPi, slot), (size_t)ne * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vI.data(), slot_region(d, d.vIdx, slot), (size_t)nv * 2, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vN.data(), slot_region(d, d.vN, slot), (size_t)nv * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vC.data(), slot_region(d, d.vChild, slot), (size_t)nv * 4, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vQ.data(), slot_region(d, d.vQ, slot), (size_t)nv * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vP.data(), slot_region(d, d.vP, slot), (size_t)nv * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) {
         const NodeHdr &h = hdr[i];
         const u32 *k = key.data() + (size_t)i * d.KW;

@@ -82,7 +82,7 @@ class _Group:
 
 class BatchedSelfPlay:
     def __init__(self, game, nnet, args, games, move_rule=_lib.MOVE_SAMPLE, seed=0, node_cap=0, edge_cap=0, max_examples=0,
-                 use_graph=True, groups=2, step_cap=16, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, compact_rows=True, channels_last=True, resblock_kernel=True, device=None,
+                 use_graph=True, groups=2, step_cap=4, use_stem=True, fuse_elementwise=True, dense_small_convs=True, reclaim=True, vis_cap=0, compact_rows=True, channels_last=True, resblock_kernel=True, device=None,
                  tie_salt=None, host_evaluator=None):
         """host_evaluator: optional callable (rows [n][H] uint64, remaining [n][N] uint8, slots [n]) -> (pi [n][A] float32, v [n]
         float32) that replaces the CNN -- any object with the reference's `predict` contract can sit behind it; the waves then run
