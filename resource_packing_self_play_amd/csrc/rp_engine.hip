@@ -170,6 +170,12 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // index of this wave in its workgroup, as a wave-uniform (SGPR) value: everything derived from it -- the slot id, the slot's region
 // pointers -- then lives in scalar registers; derived from threadIdx.x alone the compiler keeps all of it per lane
 __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// A value every lane of the wave holds (loaded from a wave-uniform address, broadcast by lane 0 ...) moved to scalar registers: the
+// compiler cannot prove that a vector load returned one value, so without this every branch, loop bound and address derived
+// from a node header or a slot's state is per-lane VALU work behind exec masks.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | (u64)uni((u32)v); }
 __device__ __forceinline__ void wave_sync() {
     // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
     // memory operations across the point and makes earlier stores visible to the other lanes.
@@ -441,8 +447,8 @@ __device__ u32 arena_reserve(const Arena &a, int d, u32 need, u32 *room) {
         }
         if (c != 0xFFFFu && need <= a.chunk) { off = c * a.chunk + used; left = a.chunk - used; }
     }
-    *room = __shfl(left, 0);
-    return __shfl(off, 0);
+    *room = uni(left);  // lane 0 did the bookkeeping
+    return uni(off);
 }
 __device__ void arena_commit(const Arena &a, int d, u32 n) {
     if (lane_id() == 0) a.used[d] += n;
@@ -524,6 +530,16 @@ template <typename row_t> struct Tree {
         arena_reset(pa, p.N + 1, p.peak_chunks + (size_t)g * 2);
         arena_reset(va, p.N + 1, p.peak_chunks + (size_t)g * 2 + 1);
     }
+    // a node's header as wave-uniform scalars (one 32-byte vector load, eight readfirstlanes)
+    __device__ __forceinline__ NodeHdr load_hdr(u32 node) const {
+        static_assert(sizeof(NodeHdr) == 32, "NodeHdr is eight dwords");
+        const uint4 *q = (const uint4 *)(hdr + node);
+        const uint4 a = q[0], b = q[1];
+        u32 w[8] = {uni(a.x), uni(a.y), uni(a.z), uni(a.w), uni(b.x), uni(b.y), uni(b.z), uni(b.w)};
+        NodeHdr h;
+        __builtin_memcpy(&h, w, sizeof h);
+        return h;
+    }
     static __device__ __forceinline__ int level_of(int N, u64 rem0, u64 rem1) { return N - __popcll(rem0) - __popcll(rem1); }
 
     // key of a node -> lane-resident rows + uniform remaining words
@@ -537,6 +553,7 @@ template <typename row_t> struct Tree {
         rem1 = 0;
         if (p.RMW > 2) rem1 = rw[2];
         if (p.RMW > 3) rem1 |= (u64)rw[3] << 32;
+        rem0 = uni(rem0); rem1 = uni(rem1);
     }
     __device__ void store_key(u32 node, row_t myrow, u64 rem0, u64 rem1) {
         u32 *k = key + (size_t)node * p.KW;
@@ -570,7 +587,7 @@ template <typename row_t> struct Tree {
             while (cand) {
                 int l = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
-                u32 id = (u32)__shfl(e, l) - 1u;
+                u32 id = (u32)__builtin_amdgcn_readlane((int)(u32)e, l) - 1u;
                 if (key_equals(id, myrow, rem0, rem1)) return id;
             }
             if (first_empty < 64) { insert_slot = (slot + first_empty) & mask; return NONE32; }
@@ -639,8 +656,12 @@ template <typename row_t> struct Tree {
     __device__ u32 resolve_child(u32 node, u32 e, int a, bool *was_new) {
         row_t myrow; u64 rem0, rem1;
         load_key(node, myrow, rem0, rem1);
+        a = uni(a);
         int i = (int)(((u32)a * p.magicW) >> 20), j = a - i * p.W;
-        myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, wh[2 * i], wh[2 * i + 1]);
+        int iw, ih;  // the item's size: from the lanes when the kernel loaded the slot's sizes, else one dependent read
+        if (have_sizes) { iw = i < 64 ? __builtin_amdgcn_readlane(w_lo, i) : __builtin_amdgcn_readlane(w_hi, i - 64); ih = i < 64 ? __builtin_amdgcn_readlane(h_lo, i) : __builtin_amdgcn_readlane(h_hi, i - 64); }
+        else { iw = uni((int)wh[2 * i]); ih = uni((int)wh[2 * i + 1]); }
+        myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, iw, ih);
         if (i < 64) rem0 &= ~(1ull << i); else rem1 &= ~(1ull << (i - 64));
         u32 child = find_or_materialize(myrow, rem0, rem1, was_new);
         if (lane_id() == 0 && child != NONE32 && e != NONE32) vChild[e] = child;
@@ -791,7 +812,8 @@ __device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(
 // action < 0: pick by p.move_rule.  Leaves phase RUNNING, EPISODE_DONE or FAILED.
 template <typename row_t, typename CT>
 __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, CT *c) {
-    NodeHdr hd = t.hdr[root];
+    root = uni(root);
+    NodeHdr hd = t.load_hdr(root);
     const int lane = lane_id();
     u32 chosen = NONE32;  // visited entry of the move that is played
     int free_action = -1;  // legal move played from a root the search never expanded (no statistics to keep)
@@ -976,6 +998,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     t.load_sizes();
+    phase = uni(phase); root = uni(root); sims_done = uni(sims_done); t.n_nodes = uni(t.n_nodes);
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
     u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
     for (int k = 0; k < CNT_N; ++k) c[k] = 0;
@@ -995,7 +1018,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
         u32 vkind = RP_KIND_WEAK;
         bool need_eval = false, failed = false;
         for (;;) {
-            NodeHdr hd = t.hdr[node];
+            NodeHdr hd = t.load_hdr(node);
             if (hd.term != 0) {  // :81-83
                 v = (double)hd.term; vkind = hdr_term_kind(hd); c[CNT_TERMINAL]++;
                 break;
@@ -1157,9 +1180,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     u32 e0 = 0, n0 = 0, e1 = 0, n1 = 0;  // path entries of levels lane and 64 + lane (entries past `depth` are stale and unused)
     if (lane < p.N) { e0 = pe[lane]; n0 = pn[lane]; }
     if (lane + 64 < p.N) { e1 = pe[lane + 64]; n1 = pn[lane + 64]; }
-    if (phase != RP_PHASE_WAIT_EVAL) return;
+    if (uni(phase) != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
-    NodeHdr hd = t.hdr[node];
+    NodeHdr hd = t.load_hdr(uni(node));
     // backup along the stored path (:130-139) first: its loads travel with the header's
     if (lane < depth) t.backup_entry(n0, e0, v, RP_KIND_F32);
     if (lane + 64 < depth) t.backup_entry(n1, e1, v, RP_KIND_F32);
