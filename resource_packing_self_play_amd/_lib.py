@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librp_engine.so")
+# RP_ENGINE_LIB: another build of the same library (kernel experiments with different compile-time settings); must exist
+LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(HERE, "csrc", "librp_engine.so")
 ABI_VERSION = 3
 
 MOVE_EXTERNAL, MOVE_ARGMAX_FIRST, MOVE_SAMPLE = 0, 1, 2
