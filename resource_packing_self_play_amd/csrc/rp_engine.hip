@@ -106,7 +106,6 @@ struct DP {  // device view of a context, passed by value to every kernel
     // k_compact builds in slot order when the host asks for the number of waiting leaves
     int rows_identity;
     int *eval_count, *eval_slot;
-    u32 *eval_node;  // the waiting slots' leaf nodes in the same order (k_compact): a row's key address is then one load away
     // arenas: ONE slab per slot (slab_stride bytes apart) holding the slot's ten regions back to back, hottest first -- a wave's
     // accesses then fall into 2-3 translation fragments instead of ten (UTCL2 was busy 76 % of k_search with one array per
     // region across all slots); the pointers below are slot 0's regions, slot g's are slab_stride * g bytes further
@@ -1345,42 +1344,50 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
     // T_LDS: a wave per leaf.  Table in L2 (N > 40: 204 KB at N = 128): a WORKGROUP per leaf, its four waves take every fourth pass --
     // a 50x50 leaf is 25 passes x 128 items of dependent L2 reads (0.9 ms per leaf for one wave, whatever the batch size)
     const int wv_ = wave_in_block();
-    // A leaf's inputs are two dependent global round trips away (row -> slot and leaf node; then key, item sizes, phase) -- a fifth of a
-    // wave's time per leaf when they are waited for on the spot.  The waves are persistent, so the inputs are requested ahead: the
-    // (slot, node) pair two leaves ahead, the state one leaf ahead; each is first touched a whole leaf's work after its request.
+    // A leaf's inputs are three dependent global round trips away (row -> slot; slot -> leaf node, phase, item sizes; node -> key) -- a
+    // fifth of a wave's time per leaf when they are waited for on the spot.  The waves are persistent, so the inputs are requested
+    // ahead: the slot three leaves ahead, the slot's state two ahead, the key one ahead; each is first touched a whole leaf's work
+    // after its request.
     const long long stride = T_LDS ? (long long)gridDim.x * WAVES_PER_BLOCK : (long long)gridDim.x;
-    auto load_pair = [&](long long bb, int &g_raw, u32 &node_raw) {
-        g_raw = 0; node_raw = 0;
-        if (bb < limit) { g_raw = p.rows_identity ? (int)bb : p.eval_slot[bb]; node_raw = p.rows_identity ? p.leaf_node[bb] : p.eval_node[bb]; }
-    };
-    struct LeafIn { row_t row; u32 rm[4]; int wh_lo, wh_hi, phase; };
-    auto load_leaf = [&](int g, u32 node, LeafIn &L) {  // g, node: wave-uniform
-        const u32 *k = slot_region(p, p.key, g) + (size_t)node * p.KW;
-        L.row = lane < p.H ? ((const row_t *)k)[lane] : (row_t)0;
-        const u32 *rwp = k + p.H * p.RW;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) L.rm[q] = q < p.RMW ? rwp[q] : 0u;
+    auto load_slot = [&](long long bb) { return bb < limit ? (p.rows_identity ? (int)bb : p.eval_slot[bb]) : 0; };
+    struct SlotIn { u32 node; int wh_lo, wh_hi, phase; };
+    auto load_state = [&](int g, SlotIn &S) {  // g: wave-uniform
+        S.node = p.leaf_node[g]; S.phase = p.phase[g];
         // item sizes live in lanes (item i in lane i & 63), broadcast with readlane inside the uniform item loop: no memory traffic
         const u8 *wh = p.item_wh + (size_t)g * p.N * 2;
-        L.wh_lo = lane < p.N ? wh[2 * lane] | (wh[2 * lane + 1] << 8) : 0;
-        L.wh_hi = lane + 64 < p.N ? wh[2 * (lane + 64)] | (wh[2 * (lane + 64) + 1] << 8) : 0;
-        L.phase = p.phase[g];
+        S.wh_lo = lane < p.N ? wh[2 * lane] | (wh[2 * lane + 1] << 8) : 0;
+        S.wh_hi = lane + 64 < p.N ? wh[2 * (lane + 64)] | (wh[2 * (lane + 64) + 1] << 8) : 0;
+    };
+    struct KeyIn { row_t row; u32 rm[4]; };
+    auto load_key_ahead = [&](int g, u32 node, KeyIn &K) {  // g, node: wave-uniform
+        const u32 *k = slot_region(p, p.key, g) + (size_t)node * p.KW;
+        K.row = lane < p.H ? ((const row_t *)k)[lane] : (row_t)0;
+        const u32 *rwp = k + p.H * p.RW;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) K.rm[q] = q < p.RMW ? rwp[q] : 0u;
     };
     long long b = T_LDS ? (long long)blockIdx.x * WAVES_PER_BLOCK + wv_ : (long long)blockIdx.x;
-    int g_raw; u32 node_raw;
-    LeafIn nxt;
-    nxt.row = 0; nxt.rm[0] = nxt.rm[1] = nxt.rm[2] = nxt.rm[3] = 0; nxt.wh_lo = nxt.wh_hi = 0; nxt.phase = -1;
-    load_pair(b, g_raw, node_raw);
-    if (b < limit) load_leaf(uni(g_raw), uni(node_raw), nxt);
-    load_pair(b + stride, g_raw, node_raw);
+    // prologue: leaf b's chain in full, leaf b + stride up to its state, leaf b + 2 stride's slot
+    int g1 = uni(load_slot(b)), g2_raw = load_slot(b + stride), g3_raw = load_slot(b + 2 * stride);
+    SlotIn s1, s2;
+    s1.node = 0; s1.wh_lo = s1.wh_hi = 0; s1.phase = -1; s2 = s1;
+    KeyIn k1;
+    k1.row = 0; k1.rm[0] = k1.rm[1] = k1.rm[2] = k1.rm[3] = 0;
+    if (b < limit) { load_state(g1, s1); load_key_ahead(g1, uni(s1.node), k1); }
+    int g2 = uni(g2_raw);
+    if (b + stride < limit) load_state(g2, s2);
     for (; b < limit; b += stride) {
-        const LeafIn cur = nxt;
-        const int phase = uni(cur.phase);
-        const u64 rem0 = (u64)uni(cur.rm[0]) | ((u64)uni(cur.rm[1]) << 32), rem1 = (u64)uni(cur.rm[2]) | ((u64)uni(cur.rm[3]) << 32);
-        const row_t myrow = cur.row;
-        const int wh_lo = cur.wh_lo, wh_hi = cur.wh_hi;
-        if (b + stride < limit) load_leaf(uni(g_raw), uni(node_raw), nxt);
-        load_pair(b + 2 * stride, g_raw, node_raw);
+        // this leaf: everything was requested at least one leaf ago
+        const int phase = uni(s1.phase);
+        const u64 rem0 = (u64)uni(k1.rm[0]) | ((u64)uni(k1.rm[1]) << 32), rem1 = (u64)uni(k1.rm[2]) | ((u64)uni(k1.rm[3]) << 32);
+        const row_t myrow = k1.row;
+        const int wh_lo = s1.wh_lo, wh_hi = s1.wh_hi;
+        // next leaf's key (its state was requested a leaf ago), the state of the one after, the slot of the third
+        s1 = s2; g1 = g2;
+        if (b + stride < limit) load_key_ahead(g1, uni(s1.node), k1);
+        g2 = uni(g3_raw);
+        if (b + 2 * stride < limit) load_state(g2, s2);
+        g3_raw = load_slot(b + 3 * stride);
         if (phase != RP_PHASE_WAIT_EVAL) continue;
         float *ob = out + (size_t)b * STEM_C * P;
         // A lane owns the 2x2 block of convolution outputs (2pr + {0,1}, 2px + {0,1}) of pooled pixel (pr, px): every output is
@@ -1716,7 +1723,7 @@ __global__ void __launch_bounds__(1024) k_compact(DP p) {
         const int g = base + lane;
         const bool flag = g < g1 && p.phase[g] == RP_PHASE_WAIT_EVAL;
         const u64 m = __ballot(flag);
-        if (flag) { const int row = off + __popcll(m & lanes_below()); p.eval_slot[row] = g; p.eval_node[row] = p.leaf_node[g]; p.game_row[g] = row; }
+        if (flag) { const int row = off + __popcll(m & lanes_below()); p.eval_slot[row] = g; p.game_row[g] = row; }
         off += __popcll(m);
     }
     if (tid == 1023) *p.eval_count = off;
@@ -2726,7 +2733,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     A_(d.root, G); A_(d.n_nodes, G); A_(d.phase, G); A_(d.sims_done, G); A_(d.moves, G); A_(d.episode, G);
     A_(d.leaf_node, G); A_(d.path_len, G); A_(d.path_edge, G * N); A_(d.path_node, G * N); A_(d.game_row, G);
     A_(d.last_outcome, G); A_(d.last_score, G); A_(d.last_v, G); A_(d.last_vkind, G);
-    A_(d.eval_count, 1); A_(d.eval_slot, G); A_(d.eval_node, G);
+    A_(d.eval_count, 1); A_(d.eval_slot, G);
     {   // the slot slabs: one allocation, regions 256-byte aligned, hottest first (headers, hash table, visited blocks, keys, legal-move runs)
         size_t off = 0;
         auto region = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
