@@ -1709,23 +1709,50 @@ __global__ void k_items_generator(long long n, int N, int bin_w, int bin_h, cons
 __global__ void __launch_bounds__(1024) k_compact(DP p) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-    const int seg = (((p.G + 15) >> 4) + 63) & ~63, g0 = wid * seg, g1 = g0 + seg < p.G ? g0 + seg : p.G;
+    // a lane takes FOUR consecutive slots per step (one 16-byte load): 8 steps per wave at 32 768 slots instead of 32, all requested
+    // before the first is used; the 4-bit results stay in registers for the second walk (which then has no loads at all)
+    const int seg = (((p.G + 15) >> 4) + 255) & ~255, g0 = wid * seg, g1 = g0 + seg < p.G ? g0 + seg : p.G;
+    constexpr int KEEP = 16;  // steps whose flags are kept (G <= 65 536); longer segments are read again
+    u32 keep[KEEP];
+    auto flags_at = [&](int base) -> u32 {
+        const int g = base + 4 * lane;
+        u32 m = 0;
+        if (g + 3 < g1) {
+            const int4 ph = *(const int4 *)(p.phase + g);
+            m = (ph.x == RP_PHASE_WAIT_EVAL ? 1u : 0u) | (ph.y == RP_PHASE_WAIT_EVAL ? 2u : 0u) | (ph.z == RP_PHASE_WAIT_EVAL ? 4u : 0u) | (ph.w == RP_PHASE_WAIT_EVAL ? 8u : 0u);
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (g + q < g1 && p.phase[g + q] == RP_PHASE_WAIT_EVAL) m |= 1u << q;
+        }
+        return m;
+    };
     int cnt = 0;
-    for (int base = g0; base < g1; base += 64) {
-        const int g = base + lane;
-        cnt += __popcll(__ballot(g < g1 && p.phase[g] == RP_PHASE_WAIT_EVAL));
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        keep[it] = g0 + it * 256 < g1 ? flags_at(g0 + it * 256) : 0u;
+        cnt += __popc(keep[it]);
     }
+    for (int base = g0 + KEEP * 256; base < g1; base += 256) cnt += __popc(flags_at(base));
+    cnt = (int)__builtin_amdgcn_readlane((int)wave_scan_add((u32)cnt), 63);
     if (lane == 0) wsum[wid] = cnt;
     __syncthreads();
     int off = 0;
     for (int w = 0; w < wid; ++w) off += wsum[w];
-    for (int base = g0; base < g1; base += 64) {
-        const int g = base + lane;
-        const bool flag = g < g1 && p.phase[g] == RP_PHASE_WAIT_EVAL;
-        const u64 m = __ballot(flag);
-        if (flag) { const int row = off + __popcll(m & lanes_below()); p.eval_slot[row] = g; p.game_row[g] = row; }
-        off += __popcll(m);
-    }
+    auto emit = [&](int base, u32 m) {
+        const int c = __popc(m);
+        const int inc = (int)wave_scan_add((u32)c);
+        int row = off + inc - c;
+        for (u32 mm = m; mm; mm &= mm - 1) {
+            const int g = base + 4 * lane + (__ffs((int)mm) - 1);
+            p.eval_slot[row] = g; p.game_row[g] = row;
+            ++row;
+        }
+        off += __builtin_amdgcn_readlane(inc, 63);
+    };
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it)
+        if (g0 + it * 256 < g1) emit(g0 + it * 256, keep[it]);
+    for (int base = g0 + KEEP * 256; base < g1; base += 256) emit(base, flags_at(base));
     if (tid == 1023) *p.eval_count = off;
 }
 __global__ void k_reduce_counters(DP p) {  // totals over slots; one workgroup, thread k sums counter k % CNT_N over a slot stripe
