@@ -1329,7 +1329,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
     extern __shared__ __attribute__((aligned(16))) int4 sT4[];
     const int lane = lane_id();
     if (T_LDS) {
-        const int n4 = p.N * 25 * STEM_C / 4;
+        const int n4 = (p.N * 25 + 1) * STEM_C / 4;  // + the all-zero row behind the table
         const int4 *src = (const int4 *)p.stemT;
         for (int i = threadIdx.x; i < n4; i += blockDim.x) sT4[i] = src[i];
         __syncthreads();
@@ -1431,19 +1431,21 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                     for (int q = 0; q < 4; ++q) { int4 v = tb[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
                 }
             }
+            // Branch-free per item: an output's class against the rectangle is min(extent - coordinate, 2) (+ 2 in row / column 0); an
+            // output the rectangle does not reach reads the all-zero row behind the table instead of being skipped -- no exec-mask
+            // juggling around the four outputs, and the 16 loads of an item are independent of each other.
+            const int r0b = ra == 0 ? 2 : 0, c0b = xa == 0 ? 2 : 0, zrow = p.N * 25;
             for (int i = 0; i < p.N; ++i) {
                 if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
                 const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
                 const int iw = whi & 255, ih = whi >> 8;
-                const int rc0 = live ? stem_class(ra, ih) : -1, cc0 = stem_class(xa, iw);
-                if (__ballot(rc0 >= 0 && cc0 >= 0) == 0ull) continue;  // the item's rectangle (+1 border) misses every lane's block
-                if (rc0 < 0 || cc0 < 0) continue;
-                const int rc1 = rbok ? stem_class(ra + 1, ih) : -1, cc1 = xbok ? stem_class(xa + 1, iw) : -1;
+                const int dr = ih - ra, dc = iw - xa;  // >= 0: output (ra, xa) has a tap inside the rectangle
+                if (__ballot(live && dr >= 0 && dc >= 0) == 0ull) continue;  // the item's rectangle (+1 border) misses every lane's block
+                const int rcl[2] = {min(dr, 2) + r0b, min(dr - 1, 2)}, ccl[2] = {min(dc, 2) + c0b, min(dc - 1, 2)};
+                const bool rok[2] = {live && dr >= 0, rbok && dr >= 1}, cok[2] = {dc >= 0, xbok && dc >= 1};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int rc = (j >> 1) ? rc1 : rc0, cc = (j & 1) ? cc1 : cc0;
-                    if (rc < 0 || cc < 0) continue;
-                    const int trow = (i * 5 + rc) * 5 + cc;
+                    const int trow = (rok[j >> 1] && cok[j & 1]) ? i * 25 + rcl[j >> 1] * 5 + ccl[j & 1] : zrow;
                     const int4 *tt = T_LDS ? (sT4 + trow * (STEM_C / 4)) : ((const int4 *)p.stemT + (size_t)trow * (STEM_C / 4));
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { int4 v = tt[q]; acc[j][4 * q] += v.x; acc[j][4 * q + 1] += v.y; acc[j][4 * q + 2] += v.z; acc[j][4 * q + 3] += v.w; }
@@ -3070,7 +3072,7 @@ extern "C" int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const f
     if (!ctx || !conv_w_dev || !bias_dev) return fail(ctx, RP_ERR_ARG, "rp_stem_set_weights: bad argument");
     DP &d = ctx->d;
     if (!d.stemT) {
-        ALLOC(ctx, d.stemT, (size_t)d.N * 25 * STEM_C);
+        ALLOC(ctx, d.stemT, (size_t)(d.N * 25 + 1) * STEM_C);  // + one all-zero row (ALLOC clears): the target of outputs an item does not reach
         ALLOC(ctx, d.stemTB, (size_t)512 * STEM_C);
         ALLOC(ctx, d.stemBias, (size_t)STEM_C);
         ALLOC(ctx, d.stemScale, (size_t)STEM_C);
@@ -3087,7 +3089,7 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     if (!d.stemT) return fail(ctx, RP_ERR_STATE, "rp_leaf_stem: call rp_stem_set_weights first");
     long long rows = std::min<long long>(capacity_rows, d.G);
     if (rows == 0) return RP_OK;
-    const size_t t_bytes = (size_t)d.N * 25 * STEM_C * sizeof(int);
+    const size_t t_bytes = (size_t)(d.N * 25 + 1) * STEM_C * sizeof(int);  // the item table and its zero row
     const bool t_lds = t_bytes <= 64 * 1024;
     // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32), a wave per leaf; L2 form: a workgroup per leaf
     const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? 256 * 3 : 1 << 20);
