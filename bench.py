@@ -89,11 +89,18 @@ def simulate_plan(startup_s, pool_s, steps, warmup, budget_s=DEFAULT_BUDGET_S, r
     return n, warm, timed, t + reserve_s
 
 
-def engine_hash():
+def engine_hash(path=None):
+    """SHA-256 of the engine source as the compiler sees it, near enough: comments removed, runs of white space collapsed -- a
+    reworded comment does not make the committed PMC figures stale, any change of code does."""
+    import re
     try:
-        return hashlib.sha256(open(ENGINE_SRC, "rb").read()).hexdigest()
+        src = open(path or ENGINE_SRC, "r", encoding="utf-8", errors="replace").read()
     except OSError:
         return None
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"\s+", " ", src).strip()
+    return hashlib.sha256(src.encode("utf-8")).hexdigest()
 
 
 def load_pmc_traffic():

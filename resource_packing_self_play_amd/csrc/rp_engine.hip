@@ -179,8 +179,8 @@ __device__ __forceinline__ u64 uni(u64 v) { return ((u64)uni((u32)(v >> 32)) << 
 __device__ __forceinline__ void wave_sync() {
     // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
     // memory operations across the point and makes earlier stores visible to the other lanes.
-    // (A wavefront-scope fence -- no s_waitcnt vmcnt(0) -- passes every parity test and measures the same: k_search is bound by
-    // instruction issue, 3 waves x ~16 k issue cycles in a 65 k-cycle wave lifetime, not by these drains.)
+    // (A wavefront-scope fence -- no s_waitcnt vmcnt(0) -- passed every parity test and measured the same when it was tried; the
+    // workgroup scope stays because the tree kernels re-read, by other lanes, global data a lane has just stored.)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }

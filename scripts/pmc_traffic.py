@@ -39,7 +39,9 @@ def main(fetch_dir, write_dir, leaves, out):
         f_kib, w_kib = fe.get(k, (0, 0.0))[1], wr.get(k, (0, 0.0))[1]
         res[k] = {"launches": fe.get(k, (0, 0))[0], "fetch_size_kib_raw": f_kib, "write_size_kib": w_kib,
                   "hbm_bytes_per_launch": 2 * f_kib * 1024 + w_kib * 1024, "leaves_per_launch": int(leaves)}
-    doc = {"engine_sha256": hashlib.sha256(open(ENGINE_SRC, "rb").read()).hexdigest(), "kernels": res}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench  # engine_hash(): comment- and white-space-insensitive SHA-256 of the engine source (the same function checks it)
+    doc = {"engine_sha256": bench.engine_hash(ENGINE_SRC), "kernels": res}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
 

@@ -88,3 +88,16 @@ def test_gpus_flag_starts_the_ranks_itself():
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["ranks_joined"] == 2 and line["backend"] == "gloo" and line["dry_run"] is True
+
+
+def test_engine_hash_ignores_comments_but_not_code(tmp_path):
+    """profiles/pmc_traffic.json is tied to the engine source by bench.engine_hash(): rewording a comment keeps the PMC figures
+    valid, any change of code makes them stale (traffic: null)."""
+    src = open(bench.ENGINE_SRC).read()
+    a = tmp_path / "a.hip"; a.write_text(src.replace("// kernels\n", "// kernels, reworded\n\n   \n"))
+    b = tmp_path / "b.hip"; b.write_text(src.replace("#define SEARCH_WAVES 5", "#define SEARCH_WAVES 4"))
+    assert src != a.read_text() and src != b.read_text()
+    assert bench.engine_hash(str(a)) == bench.engine_hash()
+    assert bench.engine_hash(str(b)) != bench.engine_hash()
+    pmc, note = bench.load_pmc_traffic()
+    assert pmc is not None and note is None, "profiles/pmc_traffic.json does not belong to the committed rp_engine.hip"
