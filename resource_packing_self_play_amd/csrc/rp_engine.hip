@@ -9,8 +9,10 @@
 // node keys (the state), per-node CONTIGUOUS runs of the legal moves' (action u16, prior f32) -- 6 bytes
 // per legal move, written once at expansion -- and per-node blocks of VISITED edges only
 // (index, P, Q, N, child; grown by doubling), because a search visits ~2 % of the edges it creates.
-// A wave reads a node's priors and visited block as coalesced 64-lane loads.  Transpositions (the reference keys its dicts by the full state, MCTS_bpp.py:20-26,76) go through a
-// per-slot open-addressing table probed 64 slots per wave instruction.
+// A wave reads a node's priors and visited block as coalesced 64-lane loads.  Transpositions (the reference keys its dicts by the
+// full state, MCTS_bpp.py:20-26,76) go through a per-slot open-addressing table probed 64 slots per wave instruction.  A slot's
+// ten regions lie back to back in ONE slab (DP::slab_stride), and everything that is the same in all lanes of a wave -- the slot
+// id, region pointers, node headers, counters -- is kept in scalar registers (wave_in_block(), uni()).
 //
 // Numerics: compiled with -ffp-contract=off; the PUCT score is float64, Q follows the NumPy promotion
 // state machine of the reference's backup expression, the prior is renormalised in NumPy's pairwise
