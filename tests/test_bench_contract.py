@@ -68,6 +68,17 @@ def test_output_line_carries_the_contract():
     assert r["kernel"].startswith("k_resstage16")
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(out["cpu_baseline"])
     json.dumps(out)
+    # every own MFMA kernel has its line; the standalone figure (k_resstage16 alone on all rows) is attached to THAT kernel only
+    solo = {"ms_per_launch": 0.54, "leaves_per_launch": 32768, "achieved": 111.0, "frac": 0.706}
+    kms = {"k_resstage16 10x10": (0.45, 700), "k_resstage32 5x5": (0.46, 700), "k_convpool32 16->32 10x10": (0.28, 700)}
+    out = bench.build_output("c3", 20, 20, 32, 400, 10.01e6, 32768, 32768, 1, 2, 0, {"steps": 20, "warmup": 5}, 66.0, tot, 24000.0, 1, 32768,
+                             True, True, [0.4, 0.25, 1.9, 0.12], kms, solo, cpu, 0.9, 30.0, {"ranks_joined": 1})
+    assert out["roofline"]["kernel"].startswith("k_resstage32 5x5") and "standalone" not in out["roofline"]
+    rk = out["roofline_kernels"]
+    assert set(rk) == set(kms) and rk["k_resstage16 10x10"]["standalone"] == solo and "standalone" not in rk["k_convpool32 16->32 10x10"]
+    for r in rk.values():
+        assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["algorithmic_bytes_per_launch"]
+    json.dumps(out)
 
 
 def test_stale_pmc_traffic_is_not_reported(tmp_path, monkeypatch):
