@@ -185,11 +185,26 @@ def cpu_worker(cfg, episodes, seed0, budget_s):
     print(json.dumps({"episodes": done, "seconds": time.time() - t0, "expansions": expansions, "simulations": searches}))
 
 
+def host_cores():
+    """(cores this process may run on, cgroup CPU quota in cores or None).  The baseline uses every core it is allowed: the
+    affinity count, lowered to the container's CPU quota when that is smaller (more workers than the quota would only time-slice)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return aff, quota
+
+
 def run_cpu_baseline(cfg, budget_s):
-    """Spawns one single-threaded worker per host core available to this process; each plays whole episodes of the bench
-    workload for about `budget_s` seconds.  Returns the cpu_baseline object."""
-    cores = len(os.sched_getaffinity(0))
-    workers = max(1, min(cores, 32))
+    """Spawns one single-threaded worker per host core available to this process (no cap); each plays whole episodes of the
+    bench workload for about `budget_s` seconds.  Returns the cpu_baseline object."""
+    aff, quota = host_cores()
+    workers = max(1, aff if quota is None else min(aff, int(quota + 0.5) or 1))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", cfg, "--cpu-episodes", "64",
                                "--cpu-seed", str(100 + 1000 * w), "--cpu-budget", str(budget_s)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
@@ -209,10 +224,11 @@ def run_cpu_baseline(cfg, budget_s):
     exp = sum(o["expansions"] for o in outs)
     W, H, N, sims = CONFIGS[cfg][:4]
     return {"value": eps / wall, "unit": "episodes/s", "cores": len(outs), "kind": "port",
+            "host_cores_affinity": aff, "host_cpu_quota": quota,
             "expansions_per_s": exp / wall, "per_core_episodes_per_s": eps / wall / len(outs),
             "sample": "%d whole episodes of the bench workload (%dx%d, %d items, %d sims/move, seeds 100+), C oracle search + "
-                      "the same CNN via PyTorch CPU at batch 1 per leaf, one single-threaded process per core, %.1f s wall"
-                      % (eps, W, H, N, sims, wall)}
+                      "the same CNN via PyTorch CPU at batch 1 per leaf, one single-threaded process per core (%d workers = every "
+                      "core this process may use), %.1f s wall" % (eps, W, H, N, sims, len(outs), wall)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -230,16 +246,34 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RP_BENCH_T0=repr(T_PROCESS_START))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        p.wait()
-        if p.returncode != 0 and rc == 0:
-            rc = p.returncode
-    if rc != 0:  # do not leave ranks waiting in a collective for a rank that died
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    return rc
+    return wait_ranks(procs)
+
+
+def wait_ranks(procs, poll_s=0.2, grace_s=5.0):
+    """Polls ALL children: the first one that exits non-zero ends the job -- the others would sit in a collective (or the
+    rendezvous) waiting for it until the driver's limit.  They get SIGTERM, then SIGKILL after `grace_s`.  Returns that exit
+    code, or 0 when every rank ended cleanly."""
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + grace_s
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.0, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        q.wait()
+                return rc
+        if live:
+            time.sleep(poll_s)
+    return 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -262,7 +296,7 @@ def stage_kernel_flops(W, H):
 
 
 def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps, warmup, requested, dt, tot, waves_rank0, groups, slots_group0,
-                 use_stem, compact_rows, per_wave, kernel_ms, solo, cpu_base, mean_score, mean_moves, extra):
+                 use_stem, compact_rows, per_wave, kernel_ms, solo, cpu_base, mean_score, mean_moves, extra, timed_rows=None):
     """tot: counters summed over ranks for the timed pools (+ 'waves'); per_wave: mean ms per wave of (search, stem/planes,
     evaluator, commit) from the event-timed waves; kernel_ms: {kernel label: mean ms per launch} from HIP events."""
     episodes = tot["episodes"]
@@ -302,7 +336,12 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
     roof = None
     timed = {k: v for k, v in kernel_ms.items() if k in kflops}
 
+    # per-kernel figures: numerator and denominator from the SAME launches -- the leaves waiting in the event-timed waves themselves
+    # (read back with rp_leaf_count_async), not the mean over all waves
+    krows = timed_rows if (timed_rows and compact_rows) else rows
+
     def kernel_roofline(kname):
+        rows = krows
         kms, klaunches = timed[kname]
         ach = rows * kflops[kname] / (kms * 1e-3) / 1e12
         traffic = None
@@ -371,6 +410,72 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# --coach-iter: one CoachBPP iteration at the configuration's scale (BASELINE configs[3]: data-parallel self-play, RCCL all-gather of
+# the replay, all-reduce of the gradients)
+# ---------------------------------------------------------------------------------------------------------------------
+def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start):
+    import torch
+    import torch.distributed as dist
+    from resource_packing_self_play_amd import distributed as rdist
+    from resource_packing_self_play_amd.CoachBPP import CoachBPP
+    from resource_packing_self_play_amd.binpacking.BinPackingGame import ItemsGenerator
+    node_cap = sims * (N + 1) + 2
+    pow2 = lambda v: 1 << max(0, int(v - 1).bit_length())
+    pchunk, vchunk = max(4096, pow2(W * N)), max(1024, pow2(W * N))
+    edge_cap = max(node_cap * a.edge_factor, (min(sims, N) + 3) * pchunk)
+    vis_cap = max(int(node_cap * a.vis_factor), (min(sims, N) + 3) * vchunk)
+    n_eps = games * world
+    args = nnet.args
+    args.update(numIters=1, numEps=n_eps, iterStepThreshold=1 << 30, binH_min=H, binH=H, numScoresForRank=100, numItems=N,
+                numItersForTrainExamplesHistory=50, maxlenOfQueue=200000, epochs=1, batch_size=64, max_train_steps_per_epoch=a.train_steps,
+                checkpoint=os.environ.get("RP_BENCH_CKPT", "/tmp/rp_bench_coach_r%d" % rank), games_per_gpu=games, node_cap=node_cap, edge_cap=edge_cap,
+                vis_cap=vis_cap, groups=a.groups, use_graph=not a.no_graph, sample_seed=12345)
+    gen = ItemsGenerator(W, H, N)
+    coach = CoachBPP(game, nnet, gen.items_generator(100), W * H, gen, args, saved_rewards_list=list(rank_buffer()))
+    if world > 1:
+        rdist.attach(nnet)
+        nnet.grad_hook.timing = []
+    coach.drawIteration = lambda: (H, list(range(100, 100 + n_eps)))  # the bench's instances: seeds 100 + global episode index, full-height rectangle
+    sp = coach._driver(n_eps)
+    sp.prepare()  # evaluator warm-up + graph capture outside the timed iteration
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    coach.learn()
+    torch.cuda.synchronize(dev)
+    wall = time.time() - t0
+    tm = coach.timings[-1]
+    hook = nnet.grad_hook
+    ar_ms = [e0.elapsed_time(e1) for e0, e1 in hook.timing] if (hook is not None and hook.timing) else []
+    play_s, exch_ms, train_s, wall_max = allreduce([tm["selfplay_s"], tm["exchange"]["ms"], tm.get("train_s", 0.0), wall], dist.ReduceOp.MAX)
+    ar_mean = allreduce([float(np.mean(ar_ms)) if ar_ms else 0.0], dist.ReduceOp.MAX)[0]
+    c = sp.counters()
+    exp_tot, sim_tot = allreduce([float(c["expansions"]), float(c["simulations"])], dist.ReduceOp.SUM)
+    if rank != 0:
+        return
+    steps = int(tm.get("train_steps", 0))
+    grad_bytes = 4 * sum(p.numel() for p in nnet.nnet.parameters())
+    out = {"metric": "self-play episodes/sec of one CoachBPP iteration (with the iteration's replay exchange and training alongside)",
+           "value": n_eps / play_s, "unit": "episodes/s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": wall_max * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64 PUCT / f32 Q + CNN, u32 bit-board", "data": "synthetic",
+           "config": {"workload": "%s: one CoachBPP iteration, %dx%d bin, %d items, %d MCTS sims/move, numEps = %d (%d concurrent games per GPU x %d ranks), "
+                                  "replay all-gather + %d optimiser steps of batch 64 with gradient all-reduce" % (a.config, W, H, N, sims, n_eps, games, world, steps),
+                      "parallelism": "dp%d (episodes sharded; all-gather of the packed replay, all-reduce of the gradients)" % world},
+           "requested": requested, "ranks_joined": joined, "backend": dist.get_backend() if dist.is_initialized() else None,
+           "coach": {"numEps": n_eps, "selfplay_s": play_s, "expansions_per_s": exp_tot / play_s, "simulations_per_s": sim_tot / play_s,
+                     "examples": tm["examples"], "replay_bytes": tm["replay_bytes"], "replay_bytes_per_example": tm["replay_bytes"] / max(tm["examples"], 1),
+                     "dense_bytes_per_example": 4 * ((N + 1) * H * W + W * N + 1),
+                     "allgather_bytes_sent_per_rank": tm["exchange"]["bytes_sent"], "allgather_bytes_received_per_rank": tm["exchange"]["bytes_received"],
+                     "allgather_ms": exch_ms, "train_set_examples": tm.get("train_examples"), "train_set_bytes": tm.get("train_set_bytes"),
+                     "maxlenOfQueue": 200000, "train_steps": steps, "train_s": train_s, "train_steps_per_s": steps / train_s if train_s > 0 else None,
+                     "grad_allreduce_bytes": grad_bytes + 8, "grad_allreduce_ms_per_step": ar_mean if ar_ms else None, "grad_allreduce_calls": len(ar_ms),
+                     "iteration_wall_s": wall_max, "mean_score": float(np.mean(coach.iteration_scores[-1]))},
+           "wall_s_since_start": time.time() - t_start, "device_bytes": sp.device_bytes}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,7 +483,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--budget", type=float, default=float(os.environ.get("RP_BENCH_BUDGET_S", DEFAULT_BUDGET_S)),
                     help="wall budget in seconds from process start; whole pools are played while the next one fits")
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="default c3 (c4 with --coach-iter)")
     ap.add_argument("--games", type=int, default=0, help="concurrent game slots per GPU (default: the configuration's, 32 768 for c3)")
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
@@ -402,6 +507,9 @@ def parse_args(argv=None):
     ap.add_argument("--profile-waves", type=int, default=0, help="profiling aid: stop after this many waves per group and print no metric")
     ap.add_argument("--waves", type=int, default=0, help="bounded run for configurations whose pool takes many minutes (c5: ~100 k waves): play this many waves of "
                     "one pool and report expansions/s and simulations/s of that window (no episodes/s: no episode ends inside it)")
+    ap.add_argument("--coach-iter", action="store_true", help="time ONE CoachBPP iteration (CoachBPP.py:123-176) instead of self-play pools: self-play of numEps = "
+                    "games x ranks episodes, the replay all-gather, training steps with the gradient all-reduce; default configuration c4 (BASELINE configs[3])")
+    ap.add_argument("--train-steps", type=int, default=200, help="--coach-iter: optimiser steps that are timed (the reference's epochs x len / batch would be ~30 000)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (ranks, process group, collectives, JSON line) without the GPU work")
     ap.add_argument("--cpu-worker", default=None)
     ap.add_argument("--cpu-episodes", type=int, default=1)
@@ -412,6 +520,7 @@ def parse_args(argv=None):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
+    a.config = a.config or ("c4" if a.coach_iter else "c3")
     if a.cpu_worker:
         return cpu_worker(a.cpu_worker, a.cpu_episodes, a.cpu_seed, a.cpu_budget)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become one (this process never touches the GPU)
@@ -425,10 +534,13 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu_base = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.sims and not a.dry_run:  # N = 1 only, before this process touches the GPU
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.sims and not a.dry_run and not a.coach_iter:  # N = 1 only, before this process touches the GPU
         cpu_base = run_cpu_baseline(a.config, a.cpu_budget)
     t_cpu_done = time.time()
 
+    if a.dry_run and os.environ.get("RP_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        print("rank %d: failing on purpose (RP_BENCH_FAIL_RANK)" % rank, file=sys.stderr)
+        sys.exit(3)
     import torch
     import torch.distributed as dist
     from resource_packing_self_play_amd import distributed as rdist
@@ -468,6 +580,11 @@ def main(argv=None):
     args = Args(numMCTSSims=sims, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=64)
     torch.manual_seed(0)
     nnet = NNetWrapper(game, args)
+    if a.coach_iter:
+        coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     pool = a.pool or games
     node_cap = sims * (N + 1) + 2
     edge_cap, vis_cap = node_cap * a.edge_factor, int(node_cap * a.vis_factor)
@@ -485,6 +602,8 @@ def main(argv=None):
     phase_ms = np.zeros(4)  # search, planes, evaluator, commit
     phase_n = 0
     kev, kernel_ms = [], {}
+    cnt_host = torch.zeros(1 << 16, dtype=torch.int32).pin_memory()  # waiting leaves of every event-timed wave (ring)
+    cnt_used = [0]
 
     def play_pool(pool_idx, timed, max_waves=0):
         nonlocal phase_ms, phase_n
@@ -500,6 +619,8 @@ def main(argv=None):
                     with torch.cuda.stream(g0.stream):
                         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
                         ev[0].record(); g0.eng.search_step(sync=False)
+                        if sp.compact_rows:
+                            g0.eng.leaf_count_async(cnt_host, cnt_used[0] % cnt_host.numel()); cnt_used[0] += 1
                         ev[1].record(); g0.eng.leaf_stem(g0.stem.data_ptr(), g0.G, g0.stem_relu.data_ptr() if g0.stem_relu is not None else None, g0.channels_last) if g0.use_stem else g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
                         g0.eng.kernel_events = kev
                         ev[2].record(); pi, v = g0.forward(sp.nnet)
@@ -573,7 +694,7 @@ def main(argv=None):
     if a.warm_waves > 0 and not a.profile_waves:
         play_pool(0, True, max_waves=a.warm_waves)
         sp.pop_finished()
-        phase_ms[:] = 0; phase_n = 0; del kev[:]; kernel_ms.clear()
+        phase_ms[:] = 0; phase_n = 0; del kev[:]; kernel_ms.clear(); cnt_used[0] = 0
     sp.counters(reset=True)
     names = list(_lib.COUNTER_NAMES)
     barrier()
@@ -622,13 +743,19 @@ def main(argv=None):
             per_wave = phase_ms / max(phase_n, 1)
             kms = {k: (float(np.mean(v)), len(v)) for k, v in kernel_ms.items()}
             sc = scores[warm:]
-            extra = {"ranks_joined": joined, "pools_played": n_done, "pool_seconds": [b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:])],
+            cut = (not go) and n_done < a.steps + a.warmup
+            extra = {"ranks_joined": joined, "pools_played": n_done, "pools_planned": a.steps + a.warmup, "budget_cut": bool(cut),
+                     "steps_note": ("one step is a whole pool of %d episodes (%.1f s here): the requested %d + %d pools do not fit the %.0f s wall "
+                                    "budget that keeps this command under the driver's limit, so %d pools were played and the last %d are timed"
+                                    % (pool, longest, a.steps, a.warmup, a.budget, n_done, timed)) if cut else None,
+                     "pool_seconds": [b1 - b0 for b0, b1 in zip(bounds[:-1], bounds[1:])],
                      "warmup_pass_waves": a.warm_waves, "wall_s_since_start": time.time() - t_start, "startup_s": bounds[0] - t_start,
                      "cpu_baseline_s": t_cpu_done - t_start, "device_bytes": sp.device_bytes, "arena_peak_per_slot": sp.arena_peak(),
                      "final": not go}
             out = build_output(a.config, W, H, N, sims, flops_leaf, games, pool, world, timed, warm, requested, dt, tot, float(delta[-1]),
                                len(sp.groups), sp.groups[0].G, sp.use_stem, sp.compact_rows, per_wave, kms, solo, cpu_base,
-                               float(np.mean([s[0] for s in sc])), float(np.mean([s[1] for s in sc])), extra)
+                               float(np.mean([s[0] for s in sc])), float(np.mean([s[1] for s in sc])), extra,
+                               timed_rows=float(cnt_host[:min(cnt_used[0], cnt_host.numel())].double().mean()) if cnt_used[0] else None)
             print(json.dumps(out), flush=True)
         if not go:
             break

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 3  /* 3: fragment orders of rp_nn_pack_conv16 / 32 changed, rp_examples_meta added */
+#define RP_ABI_VERSION 4  /* 4: sparse replay buffer (rp_config.max_sparse, rp_examples_packed*, rp_expand_examples), rp_leaf_count_async */
 
 typedef enum rp_status {
     RP_OK = 0,
@@ -81,6 +81,8 @@ typedef struct rp_config {
     int32_t vis_cap;       /* per-game visited-edge arena (26-byte entries); 0 = automatic */
     void *stream;          /* hipStream_t; NULL = the default stream */
     int64_t max_examples;  /* capacity of the replay buffer in examples; 0 = none recorded */
+    int64_t max_sparse;    /* capacity of the replay buffer's pool of (action, visit count) pairs -- one per visited root edge of every
+                              recorded example; 0 = automatic (max_examples x min(A, sims + 1, 64)) */
 } rp_config;
 
 typedef struct rp_ctx rp_ctx;
@@ -169,6 +171,9 @@ int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out);
  * BinPackingGame.getBinItem + NNet.predict's view (BinPackingGame.py:118-120, NNet.py:77-79),
  * into caller-owned DEVICE memory (capacity_rows rows). */
 int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_rows);
+/* Measurement aid: enqueues a copy of the current number of waiting leaves (the device-side count of rp_set_compact_rows /
+ * rp_search_step) into HOST memory (pinned, or the copy synchronises) without waiting for it. */
+int rp_leaf_count_async(rp_ctx *ctx, int32_t *count_host);
 /* Evaluator stem on device: the network's first convolution + max-pool (BinpackingNNet.py:34,39-40:
  * conv_seqs[0].conv 3x3 pad 1, N+1 -> 16 channels, then max_pool2d(3, stride 2, pad 1)) evaluated straight from the packed
  * leaf states, exploiting that item planes are origin-anchored rectangles (tabulated tap sums).  rp_stem_set_weights reads
@@ -265,6 +270,28 @@ int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes
  * (episode, move) before they trim to maxlenOfQueue (CoachBPP.py:122). */
 int rp_examples_meta(rp_ctx *ctx, int64_t first, int64_t count, uint64_t *episode_id_out, int32_t *move_out);
 int rp_examples_clear(rp_ctx *ctx);
+/* The replay buffer in its PACKED form -- what ranks exchange and what the history of CoachBPP.learn keeps (CoachBPP.py:152-157), ~0.4 KB
+ * per example at 20x20 / 32 items where the dense training tensors of rp_examples_tensors take 55 KB:
+ *   key      u32 [E][KW]    the recorded state as the engine keys it: H row masks (u32 for W <= 32, else u64) then ceil(N / 32) words of
+ *                           remaining-item bits (KW = H * (W > 32 ? 2 : 1) + ceil(N / 32), rounded up to even when W > 32)
+ *   item_wh  u8  [E][N][2]  the episode's item sizes (getInitItems, BinPackingGame.py:37-51)
+ *   value    i32 [E]        the episode's ranked outcome (CoachBPP.py:99)
+ *   sp_off / sp_n i32 [E]   first entry and number of entries of the example's visit counts in the pool
+ *   sp_act u16 / sp_cnt u32 [S]   pool of (action, Nsa) pairs, one per visited root edge (counts of MCTS_bpp.py:40-41; a one-hot (a, 1) for
+ *                           greedy examples, :43-49)
+ *   episode i64 / move i32 [E]    may be NULL
+ * rp_examples_packed_count returns E and S; rp_examples_packed copies everything recorded so far into caller-owned DEVICE buffers of
+ * those sizes (device-to-device, on the context's stream). */
+int rp_examples_packed_count(rp_ctx *ctx, int64_t *n_examples_out, int64_t *n_sparse_out);
+int rp_examples_packed(rp_ctx *ctx, int64_t n_examples, int64_t n_sparse, uint32_t *key_dev, uint8_t *item_wh_dev, int32_t *value_dev,
+                       int32_t *sp_off_dev, int32_t *sp_n_dev, uint16_t *sp_act_dev, uint32_t *sp_cnt_dev, int64_t *episode_dev, int32_t *move_dev);
+/* Training minibatch out of a packed replay set (the examples argument of NNetWrapper.train, NNet.py:27-67, picked by the index draw of
+ * :43): row k of the outputs = example index_dev[k] (NULL: example k) of the caller-owned packed arrays above (sp_off 64-bit here: sets
+ * gathered from several ranks and iterations outgrow 32 bits), expanded exactly like rp_examples_tensors.  Stateless: uses only the
+ * context's geometry and stream. */
+int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, const uint32_t *key_dev, const uint8_t *item_wh_dev, const int32_t *value_dev,
+                       const int64_t *sp_off_dev, const int32_t *sp_n_dev, const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev,
+                       float *pi_dev, float *value_out_dev);
 
 /* ---- inspection (parity tests) --------------------------------------------------------- */
 /* Sizes of slot g's tree: nodes in use and the span of its legal-move arena (the index range of rp_dump_tree's edge arrays). */

@@ -10,7 +10,12 @@ entropy:
     it stood when the iteration began; scores are appended in episode order afterwards (the reference appends after
     each sequential episode, CoachBPP.py:134);
   * moves are sampled with the engine's counter-based RNG instead of `np.random.seed(); np.random.choice`
-    (CoachBPP.py:86-87), greedy ties go to the lowest action instead of a random one (MCTS_bpp.py:45-46);
+    (CoachBPP.py:86-87): the draw of (episode, move) is a function of (sample seed, running episode number, move), the running
+    number counts every episode this Coach has played (so iterations never reuse a stream) and the sample seed comes from OS
+    entropy like the reference's draws unless `args.sample_seed` pins it; greedy ties go to the lowest action instead of a
+    random one (MCTS_bpp.py:45-46);
+  * the replay set is kept PACKED (replay.PackedReplay: state key, item sizes, sparse visit counts -- ~0.4 KB per example
+    instead of the reference's 110 KB of int64 planes + float list) and expanded to planes / pi per training minibatch;
   * the per-episode generator seeds are drawn up front from one OS-seeded stream (`drawIteration`);
   * with several ranks a training step still covers `batch_size` examples: one index stream shared by all ranks, each rank
     takes every world-th index, gradients are summed (see `NNetWrapper.train_tensors`).
@@ -29,6 +34,14 @@ from .MCTS_bpp import MCTS
 log = logging.getLogger(__name__)
 
 
+def _opt(args, name, default):
+    """Optional attribute of an args object; the reference's own dotdict (utils.py:20-22) raises KeyError, not AttributeError."""
+    try:
+        return getattr(args, name)
+    except (AttributeError, KeyError):
+        return default
+
+
 class CoachBPP:
     def __init__(self, game, nnet, items_list, total_area, gen, args, saved_rewards_list=[]):
         self.game = game
@@ -39,7 +52,9 @@ class CoachBPP:
         self.rewards_list = list(saved_rewards_list)
         self.ep_score = 0
         self.mcts = MCTS(self.game, self.nnet, self.args)
-        self.trainExamplesHistory = []  # one (planes, pi, value) tensor triple per iteration (device tensors)
+        self.trainExamplesHistory = []  # one PackedReplay per iteration (device tensors; .dense() gives planes / pi / value)
+        self.episodes_played = 0  # running episode number: the base of an iteration's global episode ids (sampling streams)
+        self.timings = []  # per iteration: self-play seconds, replay exchange bytes / ms, training seconds and steps
         self.skipFirstSelfPlay = False
         self.gen = gen
         self.metrics_log = []  # dicts with the reference's W&B metric names, one per iteration
@@ -65,20 +80,41 @@ class CoachBPP:
                 return [(x[0], x[1], r) for x in trainExamples]
 
     # ---- batched iteration ------------------------------------------------------------------------------------------
+    def _sample_seed(self):
+        """Seed of the move-sampling streams, the same on every rank: args.sample_seed if given, else OS entropy drawn on rank 0
+        (the reference reseeds from OS entropy before every np.random.choice, CoachBPP.py:86-87)."""
+        import torch
+        s = _opt(self.args, "sample_seed", None)
+        if s is None:
+            s = int.from_bytes(os.urandom(7), "little")
+            if rdist.world_size() > 1:
+                t = torch.tensor([s], dtype=torch.int64, device=self.nnet.device)
+                torch.distributed.broadcast(t, src=0)
+                s = int(t.item())
+        return int(s) & 0x7FFFFFFFFFFFFFFF
+
     def _driver(self, n_eps):
+        """The batched self-play driver, sized for `n_eps` episodes per iteration; rebuilt when a later iteration asks for more."""
+        world = rdist.world_size()
+        per_rank = max(1, (int(n_eps) + world - 1) // world)
+        if self._selfplay is not None and per_rank > self._selfplay_per_rank:
+            self._selfplay.close()
+            self._selfplay = None
         if self._selfplay is None:
             from .selfplay import BatchedSelfPlay
-            world = rdist.world_size()
-            per_rank = (int(n_eps) + world - 1) // world
-            games = int(getattr(self.args, "games_per_gpu", 0) or per_rank)
+            if not hasattr(self, "_seed"):
+                self._seed = self._sample_seed()
+            games = min(int(_opt(self.args, "games_per_gpu", 0) or per_rank), per_rank)
             moves_cap = self.game.num_items
-            self._selfplay = BatchedSelfPlay(self.game, self.nnet, self.args, games=min(games, per_rank), move_rule=_lib.MOVE_SAMPLE,
-                                             seed=int(getattr(self.args, "seed", 0) or 0) * 1000003 + 17,  # the same on every rank
-                                             node_cap=int(getattr(self.args, "node_cap", 0) or 0),
-                                             edge_cap=int(getattr(self.args, "edge_cap", 0) or 0),
-                                             max_examples=2 * per_rank * moves_cap, use_graph=bool(getattr(self.args, "use_graph", True)),
-                                             groups=int(getattr(self.args, "groups", 2) or 2),
-                                             tie_salt=getattr(self.args, "tie_salt", None), host_evaluator=getattr(self.args, "host_evaluator", None))
+            self._selfplay = BatchedSelfPlay(self.game, self.nnet, self.args, games=games, move_rule=_lib.MOVE_SAMPLE,
+                                             seed=self._seed,  # the same on every rank
+                                             node_cap=int(_opt(self.args, "node_cap", 0) or 0),
+                                             edge_cap=int(_opt(self.args, "edge_cap", 0) or 0), vis_cap=int(_opt(self.args, "vis_cap", 0) or 0),
+                                             max_examples=per_rank * moves_cap + 64, use_graph=bool(_opt(self.args, "use_graph", True)),
+                                             groups=max(1, min(int(_opt(self.args, "groups", 2) or 2), games)),
+                                             tie_salt=_opt(self.args, "tie_salt", None), host_evaluator=_opt(self.args, "host_evaluator", None))
+            self._selfplay_per_rank = per_rank
+            self._move_mode = None
         return self._selfplay
 
     def drawIteration(self):
@@ -95,18 +131,16 @@ class CoachBPP:
         return int(draw[0]), [int(x) for x in draw[1:]]
 
     def selfPlayIteration(self, i, draws=None, move_rule=None):
-        """Self-play of iteration i: returns (ep_scores in episode order, (planes, pi, value) of all ranks in the reference's order:
-        episode by episode, move by move).  draws: (generator height, seeds) instead of drawIteration()'s (tests pin the
+        """Self-play of iteration i: returns (ep_scores in episode order, the PackedReplay of all ranks' examples in the reference's
+        order: episode by episode, move by move).  draws: (generator height, seeds) instead of drawIteration()'s (tests pin the
         reference's captured draws); move_rule: overrides sampling / greedy (tests: argmax moves with proportional targets)."""
+        import time
         import torch
         args = self.args
         bin_height, seeds = self.drawIteration() if draws is None else (int(draws[0]), [int(x) for x in draws[1]])
         n_eps = len(seeds)
         self.gen.bin_height = bin_height  # :118
         self.items_total_area = self.gen.bin_height * self.gen.bin_width  # :119
-        state = np.random.get_state()  # items_generator reseeds the global stream (BinPackingGame.py:258)
-        wh = np.array([[it[:2] for it in self.gen.items_generator(s)] for s in seeds], dtype=np.uint8)  # :127-130
-        np.random.set_state(state)
         mine = rdist.shard(n_eps)
         sp = self._driver(n_eps)
         greedy = i > args.iterStepThreshold  # :132
@@ -115,31 +149,54 @@ class CoachBPP:
             sp.set_move_rule(mode[0], onehot_examples=mode[1])  # re-captures the waves
             self._move_mode = mode
         sp.clear_examples()
-        first = mine[0] if mine else 0  # episode ids are global: first .. first + len(mine) - 1
-        ids, outcome, score, moves, stats = sp.run(wh[mine], np.full(len(mine), self.items_total_area, np.int32), self.rewards_list,
-                                                   first_id=first)
+        # global episode ids: base + index, base = the episodes this Coach has played so far -- the sampling stream of (episode, move)
+        # is never reused by a later iteration, and does not depend on which rank or slot plays the episode
+        base = self.episodes_played
+        self.episodes_played += n_eps
         dev = self.nnet.device
-        mine_t = torch.as_tensor(mine, dtype=torch.int64, device=dev)
-        local = torch.zeros(len(mine), dtype=torch.float64, device=dev)
-        local[torch.as_tensor(ids.astype(np.int64) - first, device=dev)] = torch.as_tensor(score, device=dev)
-        planes, pi, value, ex_ep, ex_mv = sp.examples(with_meta=True)
-        key = torch.as_tensor(ex_ep.astype(np.int64) * (self.game.num_items + 1) + ex_mv.astype(np.int64), device=dev)
+        t0 = time.time()
+        if mine:
+            first = base + mine[0]
+            seeds_mine = np.asarray([seeds[k] for k in mine], dtype=np.uint32)
+            from .binpacking.BinPackingGame import ItemsGenerator
+            if _opt(args, "host_items", False) or not isinstance(self.gen, ItemsGenerator):  # instances through gen.items_generator on the host (:127-130)
+                state = np.random.get_state()  # items_generator reseeds the global stream (BinPackingGame.py:258)
+                wh = np.array([[it[:2] for it in self.gen.items_generator(int(sd))] for sd in seeds_mine], dtype=np.uint8)
+                np.random.set_state(state)
+                ids, outcome, score, moves, stats = sp.run(wh, np.full(len(mine), self.items_total_area, np.int32), self.rewards_list, first_id=first)
+            else:  # bit-identical instances generated on the device (k_items_generator), total area W * bin_height
+                ids, outcome, score, moves, stats = sp.run_from_seeds(seeds_mine, self.rewards_list, first_id=first, bin_h=bin_height, bin_w=self.gen.bin_width)
+            local = torch.zeros(len(mine), dtype=torch.float64, device=dev)
+            local[torch.as_tensor(ids.astype(np.int64) - first, device=dev)] = torch.as_tensor(score, device=dev)
+            replay = sp.examples_packed()
+        else:  # more ranks than episodes: nothing to play, but every collective below is still joined
+            from .replay import PackedReplay
+            stats = {}
+            local = torch.zeros(0, dtype=torch.float64, device=dev)
+            replay = PackedReplay.empty(self.game.bin_width, self.game.bin_height, self.game.num_items, sp.eng.KW, dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t_play = time.time() - t0
+        self.last_example_keys = replay.episode * (self.game.num_items + 1) + replay.move.to(torch.int64) - base * (self.game.num_items + 1)  # LOCAL examples (tests)
         if rdist.world_size() > 1:
+            mine_t = torch.as_tensor(mine, dtype=torch.int64, device=dev)
             gathered = rdist.all_gather_variable(torch.stack([mine_t.to(torch.float64), local], dim=1))
             ep_scores = np.zeros(n_eps)
             g = gathered.cpu().numpy()
             ep_scores[g[:, 0].astype(np.int64)] = g[:, 1]
-            planes, pi, value = rdist.all_gather_examples(planes, pi, value)
-            order = torch.argsort(rdist.all_gather_variable(key))  # rank order -> (episode, move) order, the same on every rank
-            planes, pi, value = planes.index_select(0, order), pi.index_select(0, order), value.index_select(0, order)
+            replay = rdist.all_gather_packed(replay)  # rank order -> (episode, move) order, the same on every rank
+            exch = dict(rdist.last_exchange)
         else:
             ep_scores = local.cpu().numpy()
+            exch = dict(bytes_sent=0, bytes_received=0, ms=0.0, examples=len(replay))
         self.last_stats = stats
-        self.last_example_keys = key  # episode * (N + 1) + move of every LOCAL example (tests)
-        return [float(s) for s in ep_scores], (planes, pi, value)
+        self.timings.append(dict(iteration=i, episodes=n_eps, selfplay_s=t_play, examples=len(replay), replay_bytes=replay.nbytes, exchange=exch))
+        return [float(s) for s in ep_scores], replay
 
     def learn(self):
+        import time
         import torch
+        from .replay import PackedReplay
         args = self.args
         if rdist.world_size() > 1 and getattr(self.nnet, "grad_hook", None) is None:
             rdist.attach(self.nnet)  # identical weights on every rank, gradients summed over the ranks' batch slices
@@ -157,17 +214,21 @@ class CoachBPP:
                            "min reward": float(np.min(ep_scores)), "max reward": float(np.max(ep_scores))}  # :143-147
                 self.metrics_log.append(dict(metrics, iteration=i))
                 log.info("iter %d: %s", i, metrics)
-                keep = int(args.maxlenOfQueue)  # deque(maxlen=maxlenOfQueue) (:122): the LAST maxlen examples in episode order
-                self.trainExamplesHistory.append(tuple(t[-keep:] for t in examples))
+                # deque(maxlen=maxlenOfQueue) (:122): the LAST maxlen examples in episode order
+                self.trainExamplesHistory.append(examples.tail(int(args.maxlenOfQueue)))
             if len(self.trainExamplesHistory) > args.numItersForTrainExamplesHistory:  # :154-157
                 log.warning("Removing the oldest entry in trainExamples. len(trainExamplesHistory) = %d", len(self.trainExamplesHistory))
                 self.trainExamplesHistory.pop(0)
-            planes = torch.cat([e[0] for e in self.trainExamplesHistory])
-            pi = torch.cat([e[1] for e in self.trainExamplesHistory])
-            value = torch.cat([e[2] for e in self.trainExamplesHistory])
+            train_set = PackedReplay.cat(self.trainExamplesHistory)
             if rdist.rank() == 0:
                 self.nnet.save_checkpoint(folder=args.checkpoint, filename="temp.pth.tar")  # :172
-            self.nnet.train_tensors(planes, pi, value)  # :176 (sampling is with replacement, so no shuffle is needed)
+            t0 = time.time()
+            self.nnet.train_packed(train_set)  # :176 (sampling is with replacement, so no shuffle is needed)
+            if self.nnet.device.type == "cuda":
+                torch.cuda.synchronize(self.nnet.device)
+            if self.timings:
+                self.timings[-1].update(train_s=time.time() - t0, train_steps=int(getattr(self.nnet, "last_train_steps", 0)), train_examples=len(train_set),
+                                        train_set_bytes=train_set.nbytes)
             if rdist.rank() == 0:
                 self.save_rewards_list()  # :196
 
@@ -185,7 +246,7 @@ class CoachBPP:
         import torch
         os.makedirs(self.args.checkpoint, exist_ok=True)
         path = os.path.join(self.args.checkpoint, self.getCheckpointFile(iteration) + ".examples")
-        torch.save([tuple(t.cpu() for t in e) for e in self.trainExamplesHistory], path)
+        torch.save([dict(W=e.W, H=e.H, N=e.N, flat=e.to_flat().cpu()) for e in self.trainExamplesHistory], path)
 
     def loadTrainExamples(self):
         import torch
@@ -193,5 +254,6 @@ class CoachBPP:
         if not os.path.isfile(path):
             raise FileNotFoundError('File "%s" with trainExamples not found' % path)  # the reference prompts on stdin here
         hist = torch.load(path, weights_only=True)
-        self.trainExamplesHistory = [tuple(t.to(self.nnet.device) for t in e) for e in hist]
+        from .replay import PackedReplay
+        self.trainExamplesHistory = [PackedReplay.from_flat(e["flat"].to(self.nnet.device), e["W"], e["H"], e["N"]) for e in hist]
         self.skipFirstSelfPlay = True

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RP_ENGINE_LIB: another build of the same library (kernel experiments with different compile-time settings); must exist
 LIB_PATH = os.environ.get("RP_ENGINE_LIB") or os.path.join(HERE, "csrc", "librp_engine.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MOVE_EXTERNAL, MOVE_ARGMAX_FIRST, MOVE_SAMPLE = 0, 1, 2
 PHASE_IDLE, PHASE_RUNNING, PHASE_WAIT_EVAL, PHASE_MOVE_READY, PHASE_EPISODE_DONE, PHASE_FAILED = range(6)
@@ -29,7 +29,7 @@ class RpConfig(C.Structure):
                 ("edge_cap", C.c_int32), ("move_rule", C.c_int32), ("auto_restart", C.c_int32), ("reclaim", C.c_int32),
                 ("reserved0", C.c_int32), ("seed", C.c_uint64),
                 ("tie_salt", C.c_uint64), ("device", C.c_int32), ("vis_cap", C.c_int32), ("stream", C.c_void_p),
-                ("max_examples", C.c_int64)]
+                ("max_examples", C.c_int64), ("max_sparse", C.c_int64)]
 
 
 class EngineError(RuntimeError):
@@ -87,6 +87,10 @@ _SIGS = {
     "rp_examples_tensors": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "rp_examples_meta": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "rp_examples_clear": (C.c_int, [_vp]),
+    "rp_examples_packed_count": (C.c_int, [_vp, _vp, _vp]),
+    "rp_examples_packed": (C.c_int, [_vp, _i64, _i64] + [_vp] * 9),
+    "rp_expand_examples": (C.c_int, [_vp, _i64] + [_vp] * 11),
+    "rp_leaf_count_async": (C.c_int, [_vp, _vp]),
     "rp_tree_size": (C.c_int, [_vp, _i32, _vp, _vp]),
     "rp_arena_peak": (C.c_int, [_vp, _vp, _vp, _vp]),
     "rp_dump_tree": (C.c_int, [_vp, _i32] + [_vp] * 14),
@@ -149,12 +153,15 @@ class Engine:
     """Thin object wrapper of one rp_ctx (one per process and GPU)."""
 
     def __init__(self, W, H, N, games, sims, cpuct=1.0, alpha=0.75, move_rule=MOVE_EXTERNAL, seed=0, tie_salt=0,
-                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0, reclaim=0):
+                 node_cap=0, edge_cap=0, device=0, stream=0, auto_restart=0, max_examples=0, vis_cap=0, reclaim=0, max_sparse=0):
         self.L = load()
         self.W, self.H, self.N, self.A, self.G, self.sims = int(W), int(H), int(N), int(W) * int(N), int(games), int(sims)
         self.move_rule = int(move_rule)
         cfg = RpConfig(ABI_VERSION, W, H, N, games, sims, float(cpuct), float(alpha), node_cap, edge_cap, move_rule,
-                       auto_restart, 1 if reclaim else 0, 0, seed, tie_salt, device, vis_cap, stream or None, max_examples)
+                       auto_restart, 1 if reclaim else 0, 0, seed, tie_salt, device, vis_cap, stream or None, max_examples, max_sparse)
+        self.KW = self.H * (2 if self.W > 32 else 1) + (self.N + 31) // 32
+        if self.W > 32 and self.KW % 2:
+            self.KW += 1  # 64-bit rows stay 8-byte aligned (rp_engine.h: key layout)
         h = _vp()
         rc = self.L.rp_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -371,6 +378,37 @@ class Engine:
         cl = self._bchw(x)[2] == 1 and H * W > 1
         self._ck(self.L.rp_nn_bias_pool(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()),
                                         C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, Cc, H, W, 1 if cl else 0))
+
+    def leaf_count_async(self, pinned_int32, index=0):
+        """Enqueues a copy of the device-side count of waiting leaves into element `index` of a PINNED int32 torch tensor."""
+        self._ck(self.L.rp_leaf_count_async(self.h, C.c_void_p(pinned_int32.data_ptr() + 4 * int(index))))
+
+    # ---- replay buffer, packed (torch tensors on this context's device) -----------------------------
+    def examples_packed_count(self):
+        n, s = _i64(0), _i64(0)
+        self._ck(self.L.rp_examples_packed_count(self.h, C.byref(n), C.byref(s)))
+        return n.value, s.value
+
+    def examples_packed(self, device):
+        """Everything recorded so far as a dict of device tensors in the packed layout of rp_examples_packed (+ episode, move)."""
+        import torch
+        E, S = self.examples_packed_count()
+        t = dict(key=torch.empty((E, self.KW), dtype=torch.int32, device=device), wh=torch.empty((E, 2 * self.N), dtype=torch.uint8, device=device),
+                 value=torch.empty(E, dtype=torch.int32, device=device), sp_off=torch.empty(E, dtype=torch.int32, device=device),
+                 sp_n=torch.empty(E, dtype=torch.int32, device=device), sp_act=torch.empty(S, dtype=torch.int16, device=device),
+                 sp_cnt=torch.empty(S, dtype=torch.int32, device=device), episode=torch.empty(E, dtype=torch.int64, device=device),
+                 move=torch.empty(E, dtype=torch.int32, device=device))
+        torch.cuda.synchronize(device)  # the tensors come from the caller's stream, the copies run on the context's
+        self._ck(self.L.rp_examples_packed(self.h, E, S, *[C.c_void_p(t[k].data_ptr()) for k in
+                                                           ("key", "wh", "value", "sp_off", "sp_n", "sp_act", "sp_cnt", "episode", "move")]))
+        return t
+
+    def expand_examples(self, index, key, wh, value, sp_off, sp_n, sp_act, sp_cnt, planes, pi, value_out):
+        """rp_expand_examples on torch tensors (all on this context's device; index int64 or None)."""
+        n = planes.shape[0]
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        self._ck(self.L.rp_expand_examples(self.h, n, ptr(index), ptr(key), ptr(wh), ptr(value), ptr(sp_off), ptr(sp_n), ptr(sp_act), ptr(sp_cnt),
+                                           ptr(planes), ptr(pi), ptr(value_out)))
 
     def leaf_states(self, max_rows=None):
         max_rows = self.G if max_rows is None else max_rows

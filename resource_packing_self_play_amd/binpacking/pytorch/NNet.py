@@ -59,11 +59,11 @@ class NNetWrapper(NeuralNet):
 
     def predict_from_stem(self, stem, stem_relu=None, ops=None):
         """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch.
-        With `stem_relu` (= relu(stem), also written by rp_leaf_stem) and `ops` (the engine) the element-wise work runs
-        through the engine's fused kernels."""
+        With `ops` (the engine) the element-wise work runs through the engine's fused kernels; `stem_relu` (= relu(stem), which
+        rp_leaf_stem can write alongside) is only read when stage 0 runs on the library path -- the stage kernel takes `stem` alone."""
         self.nnet.eval()
         with torch.no_grad():
-            if ops is not None and stem_relu is not None:
+            if ops is not None:
                 pi, v = self.nnet.forward_from_stem_fused(stem, stem_relu, ops)
                 return pi.contiguous(), v.reshape(-1).contiguous()
             log_pi, v = self.nnet.forward_from_stem(stem)
@@ -85,15 +85,25 @@ class NNetWrapper(NeuralNet):
         return self.train_tensors(planes.to(self.device), target_pi.to(self.device), target_v.to(self.device))
 
     def train_tensors(self, planes, target_pi, target_v):
+        """Training on dense replay tensors (the schedule is `_train_loop`'s)."""
+        return self._train_loop(planes.shape[0], lambda ids: (planes.index_select(0, ids), target_pi.index_select(0, ids), target_v.index_select(0, ids)),
+                                planes.device)
+
+    def train_packed(self, replay):
+        """Training on a PackedReplay (replay.py): every minibatch is expanded to planes / pi / value by the engine's kernel
+        (rp_expand_examples) right before its forward pass, so the replay set stays at ~0.4 KB per example instead of 55 KB."""
+        return self._train_loop(len(replay), replay.expand, replay.device)
+
+    def _train_loop(self, n, fetch, device):
         """Same schedule as the reference: a fresh Adam with default hyper-parameters (`args.lr` is never read there,
         reference :31), `epochs` x floor(len / batch_size) steps, each on `batch_size` examples drawn WITH replacement
         from NumPy's global stream (:39-43), loss = -sum(pi * log p)/B + sum((v - v_hat)^2)/B (:87-91).
+        fetch(ids) -> (planes, pi, value) of the examples `ids` (int64 device tensor).
 
         Data parallel (grad_hook set by distributed.attach): the step is STILL one batch of `batch_size` examples.  Rank 0 draws
         one seed from its global stream, every rank derives the same index stream from it and takes every world-th index of
         each batch; its loss terms are divided by the full batch size and the hook SUMS the gradients, so the update equals the
         single-process one on the same indices (up to float32 summation order) at the reference's learning rate."""
-        n = planes.shape[0]
         optimizer = optim.Adam(self.nnet.parameters())
         history = []
         world, rank = 1, 0
@@ -101,27 +111,39 @@ class NNetWrapper(NeuralNet):
         if self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
             world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
         if world > 1:
-            seed = torch.tensor([np.random.randint(1 << 31) if rank == 0 else 0], dtype=torch.int64, device=planes.device)
+            seed = torch.tensor([np.random.randint(1 << 31) if rank == 0 else 0], dtype=torch.int64, device=device)
             torch.distributed.broadcast(seed, src=0)
             draw = np.random.RandomState(int(seed.item())).randint
         B = int(self.args.batch_size)
+        self.last_train_steps = 0
         for epoch in range(self.args.epochs):
             self.nnet.train()
             pi_losses, v_losses = AverageMeter(), AverageMeter()
-            for _ in range(int(n / B)):
+            step_losses = []
+            steps = int(n / B)
+            cap = getattr(self.args, "max_train_steps_per_epoch", None)  # measurement aid (bench.py --coach-iter); the reference has no cap
+            if cap:
+                steps = min(steps, int(cap))
+            for _ in range(steps):
                 ids_all = draw(n, size=B)
-                ids = torch.as_tensor(ids_all[rank::world], device=planes.device)
-                out_pi, out_v = self.nnet(planes.index_select(0, ids))
+                ids = torch.as_tensor(ids_all[rank::world], device=device)
+                x, t_pi, t_v = fetch(ids)
+                out_pi, out_v = self.nnet(x)
                 # loss_pi / loss_v (:87-91) with the FULL batch size as the divisor: a rank's slice contributes its share
-                l_pi = -torch.sum(target_pi.index_select(0, ids) * out_pi) / B
-                l_v = torch.sum((target_v.index_select(0, ids) - out_v.view(-1)) ** 2) / B
+                l_pi = -torch.sum(t_pi * out_pi) / B
+                l_v = torch.sum((t_v - out_v.view(-1)) ** 2) / B
                 optimizer.zero_grad()
                 (l_pi + l_v).backward()
+                l_pi, l_v = l_pi.detach(), l_v.detach()
                 if self.grad_hook is not None:
-                    l_pi, l_v = self.grad_hook(self.nnet, (l_pi.detach(), l_v.detach()))
+                    l_pi, l_v = self.grad_hook(self.nnet, (l_pi, l_v))
                 optimizer.step()
-                pi_losses.update(float(l_pi), B)
-                v_losses.update(float(l_v), B)
+                step_losses.append(torch.stack([l_pi.reshape(()), l_v.reshape(())]))  # read back once per epoch: no host sync per step
+                self.last_train_steps += 1
+            if step_losses:
+                for lp, lv in torch.stack(step_losses).cpu().tolist():
+                    pi_losses.update(lp, B)
+                    v_losses.update(lv, B)
             history.append((pi_losses.avg, v_losses.avg))
             if self.log:
                 print("EPOCH ::: %d  Loss_pi=%s Loss_v=%s" % (epoch + 1, pi_losses, v_losses))

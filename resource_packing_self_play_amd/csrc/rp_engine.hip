@@ -146,7 +146,13 @@ struct DP {  // device view of a context, passed by value to every kernel
     unsigned long long *ex_count;
     u32 *ex_key;      // [max_examples][KW]
     u8 *ex_wh;        // [max_examples][N][2]
-    u32 *ex_counts;   // [max_examples][A]  root visit counts
+    // root visit counts, SPARSE: one (action, count) pair per VISITED root edge (2 % of the action space at 20x20/32: ~0.2 KB per
+    // example instead of 4 A = 2.5 KB), appended to one pool; an example holds its first entry and its entry count
+    u32 *ex_sp_off, *ex_sp_n;  // [max_examples]
+    u16 *ex_sp_act;            // [sp_cap]
+    u32 *ex_sp_cnt;            // [sp_cap]
+    unsigned long long *ex_sp_cursor;
+    long long sp_cap;
     int *ex_value;    // ranked outcome of the episode, 0 until it ends
     u64 *ex_episode;  // episode id and move number of every example: the buffer fills in completion order across slots,
     int *ex_move;     // the reference appends episode by episode, move by move (CoachBPP.py:80,133)
@@ -881,26 +887,29 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
         if (child == NONE32) { if (lane == 0) p.phase[g] = RP_PHASE_FAILED; return; }
     }
     if (p.max_examples > 0) {  // trainExamples.append([state, pi, None]) (CoachBPP.py:80)
-        unsigned long long idx = 0;
-        if (lane == 0) idx = atomicAdd(p.ex_count, 1ull);
-        idx = __shfl(idx, 0);
+        unsigned long long idx = 0, sp = 0;
+        const u32 n_sp = p.onehot_examples ? 1u : (u32)hd.vis_n;  // hd may have grown by one entry above: the header's current view
+        if (lane == 0) { idx = atomicAdd(p.ex_count, 1ull); sp = atomicAdd(p.ex_sp_cursor, (unsigned long long)n_sp); }
+        idx = __shfl(idx, 0); sp = __shfl(sp, 0);
         int mv = p.moves[g];
-        if ((long long)idx < p.max_examples && mv < p.N) {
+        if ((long long)idx < p.max_examples && mv < p.N && (long long)(sp + n_sp) <= p.sp_cap) {
             const u32 *k = t.key + (size_t)root * p.KW;
             u32 *ek = p.ex_key + (size_t)idx * p.KW;
             for (int q = lane; q < p.KW; q += 64) ek[q] = k[q];
             u8 *ew = p.ex_wh + (size_t)idx * p.N * 2;
             for (int q = lane; q < 2 * p.N; q += 64) ew[q] = t.wh[q];
-            u32 *ec = p.ex_counts + (size_t)idx * p.A;
-            for (int a = lane; a < p.A; a += 64) ec[a] = 0u;
-            wave_sync();
             if (p.onehot_examples) {
-                if (lane == 0) ec[chosen_action] = 1u;
+                if (lane == 0) { p.ex_sp_act[sp] = (u16)chosen_action; p.ex_sp_cnt[sp] = 1u; }
             } else {
-                for (u32 q = lane; q < hd.vis_n; q += 64)  // hd may have grown by one entry above: re-read the header's view
-                    ec[t.pAct[hd.prior_off + t.vIdx[hd.vis_off + q]]] = t.vN[hd.vis_off + q] & NSA_MASK;
+                for (u32 q = lane; q < n_sp; q += 64) {
+                    p.ex_sp_act[sp + q] = t.pAct[hd.prior_off + t.vIdx[hd.vis_off + q]];
+                    p.ex_sp_cnt[sp + q] = t.vN[hd.vis_off + q] & NSA_MASK;
+                }
             }
-            if (lane == 0) { p.ex_value[idx] = 0; p.ex_episode[idx] = p.episode[g]; p.ex_move[idx] = mv; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx; }
+            if (lane == 0) {
+                p.ex_sp_off[idx] = (u32)sp; p.ex_sp_n[idx] = n_sp;
+                p.ex_value[idx] = 0; p.ex_episode[idx] = p.episode[g]; p.ex_move[idx] = mv; p.slot_ex[(size_t)g * p.N + mv] = (u32)idx;
+            }
         } else if (lane == 0) {
             set_error(p, ERR_EXAMPLES_CAP);
         }
@@ -1607,30 +1616,48 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     add_counters(p, g, c);
 }
 
-// Training tensors of recorded examples: planes as getBinItem (BinPackingGame.py:118-120), pi = counts / sum in
-// float64 rounded to float32 (MCTS_bpp.py:51-54 then torch.FloatTensor, NNet.py:46), value = ranked outcome.
+// Training tensors of replay examples: planes as getBinItem (BinPackingGame.py:118-120), pi = counts / sum in float64 rounded to
+// float32 (MCTS_bpp.py:51-54 then torch.FloatTensor, NNet.py:46), value = ranked outcome.  The examples are PACKED -- key (rows +
+// remaining words), item sizes, sparse (action, count) pairs, value -- either the context's own replay buffer (rp_examples_tensors)
+// or caller-owned arrays in the same format (rp_expand_examples: a training minibatch picked by an index list out of the gathered
+// replay set).  One wave per output row.
+struct PackedEx {
+    const u32 *key;      // [E][KW]
+    const u8 *wh;        // [E][N][2]
+    const int *value;    // [E]
+    const long long *sp_off64;  // [E] first (action, count) pair of the example (caller-owned sets: 64-bit) ...
+    const u32 *sp_off32;        // ... or the context's own 32-bit offsets
+    const int *sp_n;     // [E]
+    const u16 *sp_act;   // pool
+    const u32 *sp_cnt;
+};
 template <typename row_t>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, long long first, long long count, float *planes, float *pi, float *value) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, PackedEx ex, long long first, long long count, const long long *index, float *planes,
+                                                                    float *pi, float *value) {
     const long long k = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (k >= count) return;
-    const long long idx = first + k;
+    const long long idx = index ? index[k] : first + k;
     const int lane = lane_id();
-    const u32 *key = p.ex_key + (size_t)idx * p.KW;
+    const u32 *key = ex.key + (size_t)idx * p.KW;
     row_t myrow = lane < p.H ? ((const row_t *)key)[lane] : (row_t)0;
     const u32 *rw = key + p.H * p.RW;
     u64 rem0 = rw[0], rem1 = 0;
     if (p.RMW > 1) rem0 |= (u64)rw[1] << 32;
     if (p.RMW > 2) rem1 = rw[2];
     if (p.RMW > 3) rem1 |= (u64)rw[3] << 32;
-    write_planes<row_t>(p, p.ex_wh + (size_t)idx * p.N * 2, myrow, rem0, rem1, planes + (size_t)k * (p.N + 1) * p.H * p.W);
-    const u32 *cn = p.ex_counts + (size_t)idx * p.A;
+    write_planes<row_t>(p, ex.wh + (size_t)idx * p.N * 2, myrow, rem0, rem1, planes + (size_t)k * (p.N + 1) * p.H * p.W);
+    const long long off = ex.sp_off64 ? ex.sp_off64[idx] : (long long)ex.sp_off32[idx];
+    const int n = ex.sp_n[idx];
+    float *row = pi + (size_t)k * p.A;
+    for (int a = lane; a < p.A; a += 64) row[a] = 0.f;
     u64 total = 0;
-    for (int a = lane; a < p.A; a += 64) total += cn[a];
+    for (int q = lane; q < n; q += 64) total += ex.sp_cnt[off + q];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
     const double ds = (double)total;  // counts_sum = float(sum(counts))
-    for (int a = lane; a < p.A; a += 64) pi[(size_t)k * p.A + a] = (float)((double)cn[a] / ds);
-    if (lane == 0) value[k] = (float)p.ex_value[idx];
+    wave_sync();
+    for (int q = lane; q < n; q += 64) row[ex.sp_act[off + q]] = (float)((double)ex.sp_cnt[off + q] / ds);
+    if (lane == 0) value[k] = (float)ex.value[idx];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2603,6 +2630,8 @@ struct rp_ctx {
     u8 *pool_wh;
     int *pool_area, *pool_max_h;
     int64_t pool_cap;
+    int n_cu = 256;                   // compute units and LDS bytes per CU of the device (hipDeviceProp, read once in rp_create)
+    size_t lds_per_cu = 160 * 1024;
     int compact_rows = 0;             // rp_set_compact_rows: rp_search_step(ctx, NULL) lists the waiting slots on the device too
     const int *nn_rows_dev = nullptr;  // row limit of the rp_nn_* stage kernels (eval_count) while compact rows are on
 };
@@ -2661,6 +2690,16 @@ static int pick_leaves_per_wave(long long B, int PIX, int imgw_max) {
 }
 
 static int grid_for(long long waves) { return (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
+
+// Dynamic LDS above the default 64 KB limit has to be allowed per kernel; a size the device cannot give is an argument error with
+// the figures in the message, not a launch failure later.
+static int allow_lds(rp_ctx *ctx, const void *fn, size_t lds, const char *what) {
+    if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "%s: needs %zu bytes of LDS per workgroup, the device has %zu per CU", what, lds, ctx->lds_per_cu);
+    if (lds <= 64 * 1024) return RP_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed: %s", what, lds, hipGetErrorString(e));
+    return RP_OK;
+}
 
 static int check_device_error(rp_ctx *ctx) {
     int e = 0;
@@ -2723,6 +2762,17 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     ctx->stream = (hipStream_t)cfg->stream;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RP_ERR_DEVICE, "hipSetDevice: %s", hipGetErrorString(e)); }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+            // gfx950 has 160 KB of LDS per CU whatever the runtime's property says (earlier CDNA parts: 64 KB, which is also what
+            // some runtimes report for every part); the larger of the two is the limit the launches are checked against
+            size_t lds = strstr(prop.gcnArchName, "gfx950") ? (size_t)160 * 1024 : (size_t)64 * 1024;
+            if (prop.maxSharedMemoryPerMultiProcessor > lds) lds = prop.maxSharedMemoryPerMultiProcessor;
+            ctx->lds_per_cu = lds;
+        }
+    }
     DP &d = ctx->d;
     memset(&d, 0, sizeof d);
     d.W = cfg->W; d.H = cfg->H; d.N = cfg->N; d.A = cfg->W * cfg->N; d.G = cfg->games; d.sims = cfg->sims;
@@ -2787,7 +2837,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     d.fin_cap = (int)std::max<size_t>(4 * G, 1024);
     A_(d.fin_count, 1); A_(d.fin_episode, d.fin_cap); A_(d.fin_outcome, d.fin_cap); A_(d.fin_moves, d.fin_cap); A_(d.fin_score, d.fin_cap);
     d.auto_restart = cfg->auto_restart; d.max_examples = cfg->max_examples > 0 ? cfg->max_examples : 0;
-    A_(d.next_instance, 1); A_(d.ex_count, 1); A_(d.slot_ex, G * N);
+    A_(d.next_instance, 1); A_(d.ex_count, 1); A_(d.ex_sp_cursor, 1); A_(d.slot_ex, G * N);
     {
         PoolDesc *pd_dev = nullptr;
         A_(pd_dev, 1);
@@ -2796,7 +2846,12 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     }
     if (d.max_examples > 0) {
         A_(d.ex_key, (size_t)d.max_examples * d.KW); A_(d.ex_wh, (size_t)d.max_examples * N * 2);
-        A_(d.ex_counts, (size_t)d.max_examples * d.A); A_(d.ex_value, (size_t)d.max_examples);
+        // sparse visit counts: at most min(A, sims + 1) root edges are ever visited; the automatic pool allows 64 per example on average
+        // (measured 20-50 at 20x20 / 32 / 400 sims) and overflow is reported as RP_ERR_CAPACITY like the example count itself
+        d.sp_cap = cfg->max_sparse > 0 ? cfg->max_sparse : d.max_examples * (long long)std::min(std::min(d.A, std::max(cfg->sims, 1) + 1), 64);
+        if (d.sp_cap > 0x7FFFFFFFLL) rc = fail(nullptr, RP_ERR_ARG, "replay buffer: %lld (action, count) pairs exceed 2^31 - 1", d.sp_cap);
+        A_(d.ex_sp_off, (size_t)d.max_examples); A_(d.ex_sp_n, (size_t)d.max_examples); A_(d.ex_sp_act, (size_t)d.sp_cap); A_(d.ex_sp_cnt, (size_t)d.sp_cap);
+        A_(d.ex_value, (size_t)d.max_examples);
         A_(d.ex_episode, (size_t)d.max_examples); A_(d.ex_move, (size_t)d.max_examples);
     }
     std::vector<int> llo, ln, sd, ss;
@@ -2822,19 +2877,18 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         return fail(nullptr, RP_ERR_DEVICE, "rp_create: device initialisation failed");
     }
     if (STAGE_BYTES(d) + 9 * 1024 > 64 * 1024) {  // A > ~6 900: static (8 KB) + staging LDS pass the default 64 KB limit
-        const int lim = (int)(STAGE_BYTES(d) + 9 * 1024);
-        if (ctx->row64) {
-            (void)hipFuncSetAttribute((const void *)k_search<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_moves<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_set_roots<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_advance<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_pool_begin<u64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-        } else {
-            (void)hipFuncSetAttribute((const void *)k_search<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_moves<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_set_roots<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_advance<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-            (void)hipFuncSetAttribute((const void *)k_pool_begin<u32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        const size_t lim = STAGE_BYTES(d) + 9 * 1024;
+        const void *fns[5];
+        if (ctx->row64) { fns[0] = (const void *)k_search<u64>; fns[1] = (const void *)k_moves<u64>; fns[2] = (const void *)k_set_roots<u64>; fns[3] = (const void *)k_advance<u64>; fns[4] = (const void *)k_pool_begin<u64>; }
+        else { fns[0] = (const void *)k_search<u32>; fns[1] = (const void *)k_moves<u32>; fns[2] = (const void *)k_set_roots<u32>; fns[3] = (const void *)k_advance<u32>; fns[4] = (const void *)k_pool_begin<u32>; }
+        for (const void *fn : fns) {
+            const int rc2 = allow_lds(ctx, fn, lim, "rp_create (legal-move staging of the tree kernels)");
+            if (rc2 != RP_OK) {
+                const std::string msg = ctx->err;
+                for (void *p : ctx->allocs) (void)hipFree(p);
+                delete ctx;
+                return fail(nullptr, rc2, "%s", msg.c_str());
+            }
         }
     }
     *out = ctx;
@@ -3070,6 +3124,12 @@ extern "C" int rp_leaf_planes(rp_ctx *ctx, float *planes_dev, int64_t capacity_r
     return RP_OK;
 }
 
+extern "C" int rp_leaf_count_async(rp_ctx *ctx, int32_t *count_host) {
+    if (!ctx || !count_host) return fail(ctx, RP_ERR_ARG, "rp_leaf_count_async: bad argument");
+    HIPCHK(ctx, hipMemcpyAsync(count_host, ctx->d.eval_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    return RP_OK;
+}
+
 extern "C" int rp_stem_set_weights(rp_ctx *ctx, const float *conv_w_dev, const float *bias_dev) {
     if (!ctx || !conv_w_dev || !bias_dev) return fail(ctx, RP_ERR_ARG, "rp_stem_set_weights: bad argument");
     DP &d = ctx->d;
@@ -3094,7 +3154,7 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     const size_t t_bytes = (size_t)(d.N * 25 + 1) * STEM_C * sizeof(int);  // the item table and its zero row
     const bool t_lds = t_bytes <= 64 * 1024;
     // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32), a wave per leaf; L2 form: a workgroup per leaf
-    const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? 256 * 3 : 1 << 20);
+    const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? ctx->n_cu * 3 : 1 << 20);
     if (ctx->row64) {
         if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
         else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
@@ -3169,10 +3229,9 @@ extern "C" int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *fr
         return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: bad argument");
     if (B == 0) return RP_OK;
     const size_t lds = ((size_t)4 * 2 * (H + 2) * (W + 2) * RB_STRIDE + (((size_t)H * W + 3) & ~(size_t)3)) * sizeof(float);
-    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resblock16: %dx%d image does not fit LDS", H, W);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds));
-    const int grid = (int)std::min<long long>((B + 3) / 4, 256LL * per_cu);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resblock16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { const int rc = allow_lds(ctx, (const void *)k_resblock16, lds, "rp_nn_resblock16"); if (rc != RP_OK) return rc; }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, ctx->lds_per_cu / lds));
+    const int grid = (int)std::min<long long>((B + 3) / 4, (long long)ctx->n_cu * per_cu);
     hipLaunchKernelGGL(k_resblock16, dim3(grid), dim3(256), lds, ctx->stream, x_dev, frag0_dev, bias0_dev, frag1_dev, bias1_dev, out_dev, out_relu_dev, (long long)B,
                        (int)H, (int)W);
     HIPCHK(ctx, hipGetLastError());
@@ -3194,11 +3253,12 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
     const size_t lds = (size_t)16 * nt * sizeof(int) + 4 * (imgw * img_bytes + RS_STRIDE * sizeof(float));
     const long long tasks = (B + imgw - 1) / imgw;
     static const int stage_wgs = getenv("RP_STAGE16_WGS") ? atoi(getenv("RP_STAGE16_WGS")) : 2;  // resident workgroups per CU (registers: 2 waves per SIMD)
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)stage_wgs, (160 * 1024) / lds));
-    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);
+    if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: a %dx%d image needs %zu bytes of LDS per workgroup, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)stage_wgs, ctx->lds_per_cu / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, (long long)ctx->n_cu * per_cu)), block(256);
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage16<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        { const int rc_ = allow_lds(ctx, (const void *)k_resstage16<NT_>, lds, "rp_nn_resstage16"); if (rc_ != RP_OK) return rc_; }                \
         hipLaunchKernelGGL((k_resstage16<NT_>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
         break;
     switch (nt) {
@@ -3234,13 +3294,13 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     imgw = pick_leaves_per_wave(B, PIX, imgw);
     const int nt = (imgw * PIX + 15) / 16;
     const size_t wf = wave_floats(imgw), lds = lds_bytes(imgw);
-    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: %dx%d image does not fit LDS", H, W);
+    if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: a %dx%d image needs %zu bytes of LDS per workgroup, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
     const long long tasks = (B + imgw - 1) / imgw;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);  // persistent waves
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, (long long)ctx->n_cu * per_cu)), block(256);  // persistent waves
 #define CP_LAUNCH(NT_, CIN_)                                                                                                                         \
     {                                                                                                                                                \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_convpool32<NT_, CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        const int rc_ = allow_lds(ctx, (const void *)k_convpool32<NT_, CIN_>, lds, "rp_nn_convpool32"); if (rc_ != RP_OK) return rc_;                \
         hipLaunchKernelGGL((k_convpool32<NT_, CIN_>), grid, block, lds, ctx->stream, x_dev, frag_dev, bias_dev, out_dev, (long long)B, (int)H,        \
                            (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                                 \
     }
@@ -3275,13 +3335,13 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
     const int imgw = pick_leaves_per_wave(B, PIX, imgw_max);
     const int nt = (imgw * PIX + 15) / 16;
     const size_t lds = lds_bytes(imgw);
-    if (lds > 160 * 1024) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: %dx%d image does not fit LDS", H, W);
+    if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: a %dx%d image needs %zu bytes of LDS per workgroup, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
     const long long tasks = (B + imgw - 1) / imgw;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, 256LL * per_cu)), block(256);  // persistent waves
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+    const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, (long long)ctx->n_cu * per_cu)), block(256);  // persistent waves
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_resstage32<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        { const int rc_ = allow_lds(ctx, (const void *)k_resstage32<NT_>, lds, "rp_nn_resstage32"); if (rc_ != RP_OK) return rc_; }                \
         hipLaunchKernelGGL(k_resstage32<NT_>, grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev,                    \
                            (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev);                                                                   \
         break;
@@ -3507,6 +3567,13 @@ extern "C" int rp_examples_count(rp_ctx *ctx, int64_t *n_out) {
     return RP_OK;
 }
 
+static PackedEx own_examples(const DP &d) {
+    PackedEx ex;
+    ex.key = d.ex_key; ex.wh = d.ex_wh; ex.value = d.ex_value; ex.sp_off64 = nullptr; ex.sp_off32 = d.ex_sp_off; ex.sp_n = (const int *)d.ex_sp_n;
+    ex.sp_act = d.ex_sp_act; ex.sp_cnt = d.ex_sp_cnt;
+    return ex;
+}
+
 extern "C" int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, float *planes_dev, float *pi_dev, float *value_dev) {
     if (!ctx || first < 0 || count < 0 || !planes_dev || !pi_dev || !value_dev) return fail(ctx, RP_ERR_ARG, "rp_examples_tensors: bad argument");
     int64_t n = 0;
@@ -3515,7 +3582,59 @@ extern "C" int rp_examples_tensors(rp_ctx *ctx, int64_t first, int64_t count, fl
     if (first + count > n) return fail(ctx, RP_ERR_ARG, "rp_examples_tensors: range [%lld,%lld) exceeds the %lld recorded examples", (long long)first, (long long)(first + count), (long long)n);
     if (count == 0) return RP_OK;
     const DP &d = ctx->d;
-    DISPATCH(ctx, k_examples, grid_for(count), d, (long long)first, (long long)count, planes_dev, pi_dev, value_dev);
+    DISPATCH(ctx, k_examples, grid_for(count), d, own_examples(d), (long long)first, (long long)count, (const long long *)nullptr, planes_dev, pi_dev, value_dev);
+    return RP_OK;
+}
+
+extern "C" int rp_examples_packed_count(rp_ctx *ctx, int64_t *n_examples_out, int64_t *n_sparse_out) {
+    if (!ctx || !n_examples_out || !n_sparse_out) return fail(ctx, RP_ERR_ARG, "rp_examples_packed_count: bad argument");
+    int rc = rp_examples_count(ctx, n_examples_out);
+    if (rc != RP_OK) return rc;
+    unsigned long long sp = 0;
+    if (ctx->d.max_examples > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(&sp, ctx->d.ex_sp_cursor, sizeof sp, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_sparse_out = std::min<int64_t>((int64_t)sp, ctx->d.sp_cap);
+    return RP_OK;
+}
+
+extern "C" int rp_examples_packed(rp_ctx *ctx, int64_t n_examples, int64_t n_sparse, uint32_t *key_dev, uint8_t *item_wh_dev, int32_t *value_dev,
+                                  int32_t *sp_off_dev, int32_t *sp_n_dev, uint16_t *sp_act_dev, uint32_t *sp_cnt_dev, int64_t *episode_dev, int32_t *move_dev) {
+    if (!ctx || n_examples < 0 || n_sparse < 0 || !key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev || !sp_act_dev || !sp_cnt_dev)
+        return fail(ctx, RP_ERR_ARG, "rp_examples_packed: bad argument");
+    int64_t n = 0, ns = 0;
+    int rc = rp_examples_packed_count(ctx, &n, &ns);
+    if (rc != RP_OK) return rc;
+    if (n_examples > n || n_sparse > ns) return fail(ctx, RP_ERR_ARG, "rp_examples_packed: %lld examples / %lld pairs asked for, %lld / %lld recorded", (long long)n_examples, (long long)n_sparse, (long long)n, (long long)ns);
+    const DP &d = ctx->d;
+    const size_t E = (size_t)n_examples;
+    if (E) {
+        HIPCHK(ctx, hipMemcpyAsync(key_dev, d.ex_key, E * d.KW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(item_wh_dev, d.ex_wh, E * d.N * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(value_dev, d.ex_value, E * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(sp_off_dev, d.ex_sp_off, E * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(sp_n_dev, d.ex_sp_n, E * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (episode_dev) HIPCHK(ctx, hipMemcpyAsync(episode_dev, d.ex_episode, E * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (move_dev) HIPCHK(ctx, hipMemcpyAsync(move_dev, d.ex_move, E * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (n_sparse) {
+        HIPCHK(ctx, hipMemcpyAsync(sp_act_dev, d.ex_sp_act, (size_t)n_sparse * 2, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(sp_cnt_dev, d.ex_sp_cnt, (size_t)n_sparse * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return RP_OK;
+}
+
+extern "C" int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, const uint32_t *key_dev, const uint8_t *item_wh_dev, const int32_t *value_dev,
+                                  const int64_t *sp_off_dev, const int32_t *sp_n_dev, const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev,
+                                  float *pi_dev, float *value_out_dev) {
+    if (!ctx || n < 0 || !key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev || !sp_act_dev || !sp_cnt_dev || !planes_dev || !pi_dev || !value_out_dev)
+        return fail(ctx, RP_ERR_ARG, "rp_expand_examples: bad argument");
+    if (n == 0) return RP_OK;
+    PackedEx ex;
+    ex.key = key_dev; ex.wh = item_wh_dev; ex.value = value_dev; ex.sp_off64 = (const long long *)sp_off_dev; ex.sp_off32 = nullptr; ex.sp_n = sp_n_dev;
+    ex.sp_act = sp_act_dev; ex.sp_cnt = sp_cnt_dev;
+    DISPATCH(ctx, k_examples, grid_for(n), ctx->d, ex, 0LL, (long long)n, (const long long *)index_dev, planes_dev, pi_dev, value_out_dev);
     return RP_OK;
 }
 
@@ -3535,6 +3654,7 @@ extern "C" int rp_examples_meta(rp_ctx *ctx, int64_t first, int64_t count, uint6
 extern "C" int rp_examples_clear(rp_ctx *ctx) {
     if (!ctx) return RP_ERR_ARG;
     HIPCHK(ctx, hipMemsetAsync(ctx->d.ex_count, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d.ex_sp_cursor, 0, sizeof(unsigned long long), ctx->stream));
     return RP_OK;
 }
 

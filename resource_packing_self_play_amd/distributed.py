@@ -80,6 +80,49 @@ def all_gather_examples(planes, pi, value):
     return p8.to(torch.float32), all_gather_variable(pi), all_gather_variable(value)
 
 
+def all_gather_bytes(flat):
+    """All-gathers one uint8 vector per rank (lengths differ); returns the list of every rank's vector in rank order."""
+    if world_size() == 1:
+        return [flat]
+    dev = flat.device
+    if _host_staged():
+        flat = flat.cpu()
+    n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
+    sizes = [torch.zeros_like(n) for _ in range(world_size())]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = (max(sizes) + 15) & ~15
+    pad = torch.zeros(cap, dtype=torch.uint8, device=flat.device)
+    pad[:flat.numel()] = flat
+    out = torch.empty(world_size() * cap, dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(out, pad) if not _host_staged() else dist.all_gather(list(out.view(world_size(), cap).unbind(0)), pad)
+    return [out[r * cap:r * cap + s].to(dev) for r, s in enumerate(sizes)]
+
+
+last_exchange = {}  # bytes this rank sent / received and the wall milliseconds of the latest all_gather_packed (bench.py --coach-iter)
+
+
+def all_gather_packed(replay):
+    """Replay exchange of one iteration: every rank's PackedReplay (replay.py: ~0.4 KB per example -- key,
+    item sizes, sparse visit counts, value, episode / move) travels as ONE flat byte vector; the result is the union, sorted into the
+    reference's order (episode by episode, move by move), identical on every rank."""
+    import time
+    from .replay import PackedReplay
+    if world_size() == 1:
+        last_exchange.update(bytes_sent=0, bytes_received=0, ms=0.0, examples=len(replay))
+        return replay
+    if replay.device.type == "cuda":
+        torch.cuda.synchronize(replay.device)
+    t0 = time.time()
+    flat = replay.to_flat()
+    parts = all_gather_bytes(flat)
+    out = PackedReplay.cat([PackedReplay.from_flat(p, replay.W, replay.H, replay.N) for p in parts]).sort_by_episode_move()
+    if replay.device.type == "cuda":
+        torch.cuda.synchronize(replay.device)
+    last_exchange.update(bytes_sent=int(flat.numel()), bytes_received=int(sum(p.numel() for p in parts)), ms=(time.time() - t0) * 1e3, examples=len(out))
+    return out
+
+
 class FlatGradAllReduce:
     """Gradient hook for NNetWrapper.train_tensors: one flat FP32 bucket, one all-reduce(sum).  Every rank's loss is already
     divided by the FULL batch size, so the sum over ranks is the gradient of the whole batch.  Scalars passed as `extra`
@@ -89,6 +132,8 @@ class FlatGradAllReduce:
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.timing = None  # a list: (start event, end event) around every all-reduce (device tensors only; bench.py --coach-iter)
+        self.calls = 0
 
     def __call__(self, module, extra=()):
         extra = tuple(extra)
@@ -108,7 +153,15 @@ class FlatGradAllReduce:
             off += n
         for k, x in enumerate(extra):
             self.flat[off + k] = x
+        timed = self.timing is not None and dev.type == "cuda"
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if timed:
+            e1.record()
+            self.timing.append((e0, e1))
+        self.calls += 1
         off = 0
         for p in self.params:
             n = p.numel()

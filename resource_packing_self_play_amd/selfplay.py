@@ -43,7 +43,11 @@ class _Group:
             self.resblock_kernel = owner.resblock_kernel
             fmt = torch.channels_last if self.channels_last else torch.contiguous_format
             self.stem = torch.zeros((games, 16, (owner.H + 1) // 2, (owner.W + 1) // 2), dtype=torch.float32, device=owner.device).contiguous(memory_format=fmt)
-            self.stem_relu = torch.zeros_like(self.stem) if owner.fuse_elementwise else None
+            # relu(stem) is only read by the library path of stage 0; k_resstage16 takes x alone and applies the ReLU itself, so with
+            # the stage kernels the engine is handed NULL and writes 6.4 KB per leaf instead of 12.8 (half of k_leaf_stem's HBM bytes)
+            self.fused = bool(owner.fuse_elementwise)
+            stage0_kernel = owner.resblock_kernel and ((owner.H + 1) // 2) * ((owner.W + 1) // 2) <= 128
+            self.stem_relu = torch.zeros_like(self.stem) if (owner.fuse_elementwise and not stage0_kernel) else None
             self.planes = None
         else:
             self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
@@ -55,12 +59,12 @@ class _Group:
             w, b = nnet.stem_params()
             self._stem_w, self._stem_b = w, b  # keep alive until the table kernel ran
             self.eng.stem_set_weights(w.data_ptr(), b.data_ptr())
-            if self.stem_relu is not None and self.channels_last and self.resblock_kernel:
+            if self.fused and self.channels_last and self.resblock_kernel:
                 self._frag_src = nnet.nnet.refresh_frags(self.eng)
 
     def forward(self, nnet):
         if self.use_stem:
-            return nnet.predict_from_stem(self.stem, self.stem_relu, self.eng if self.stem_relu is not None else None)
+            return nnet.predict_from_stem(self.stem, self.stem_relu, self.eng if self.fused else None)
         return nnet.predict_batch(self.planes)
 
     def wave_eager(self, nnet):
@@ -213,9 +217,10 @@ class BatchedSelfPlay:
             g.eng._ck(g.eng.L.rp_set_instance_pool(g.eng.h, wh_g.shape[0], _lib._ptr(wh_g), _lib._ptr(area_g), self.first_id + lo))
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
-    def start_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None):
-        """Like start(), with instance i = ItemsGenerator.items_generator(seeds[i]) of the W x bin_h rectangle generated on the
-        device (rp_set_instance_pool_seeds: bit-identical to the host generator, tests/test_gpu_rules.py); total area W * bin_h."""
+    def start_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None, bin_w=None):
+        """Like start(), with instance i = ItemsGenerator.items_generator(seeds[i]) of the bin_w x bin_h rectangle (default: the
+        board) generated on the device (rp_set_instance_pool_seeds: bit-identical to the host generator, tests/test_gpu_rules.py);
+        total area bin_w * bin_h."""
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32).reshape(-1)
         buf = np.asarray(list(rewards_list), dtype=np.float64)
         self.first_id = int(first_id)
@@ -229,7 +234,7 @@ class BatchedSelfPlay:
                 with torch.cuda.stream(g.stream):
                     g.refresh_weights(self.nnet)
             g.eng.set_rank_buffer(buf)
-            g.eng.set_instance_pool_seeds(np.ascontiguousarray(seeds[lo:hi]), self.W, bin_h or self.H, self.first_id + lo)
+            g.eng.set_instance_pool_seeds(np.ascontiguousarray(seeds[lo:hi]), bin_w or self.W, bin_h or self.H, self.first_id + lo)
             g.eng._ck(g.eng.L.rp_begin_pool(g.eng.h))
 
     def active(self):
@@ -265,9 +270,9 @@ class BatchedSelfPlay:
         self.start(item_wh, total_area, rewards_list, first_id)
         return self._play_out(poll, max_steps)
 
-    def run_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None, poll=16, max_steps=None):
+    def run_from_seeds(self, seeds, rewards_list=(), first_id=0, bin_h=None, poll=16, max_steps=None, bin_w=None):
         """run() on device-generated instances (start_from_seeds)."""
-        self.start_from_seeds(seeds, rewards_list, first_id, bin_h)
+        self.start_from_seeds(seeds, rewards_list, first_id, bin_h, bin_w)
         return self._play_out(poll, max_steps)
 
     def _play_out(self, poll, max_steps):
@@ -286,33 +291,23 @@ class BatchedSelfPlay:
         return ids, outcome, score, moves, stats
 
     # ---- replay ---------------------------------------------------------------------------------
+    def examples_packed(self):
+        """Everything recorded so far as ONE PackedReplay (replay.py: ~0.4 KB per example) in the reference's order: episode by
+        episode, move by move (CoachBPP.py:80,133) -- the device buffers themselves fill in completion order across slots."""
+        from .replay import PackedReplay
+        torch.cuda.synchronize(self.device)
+        parts = [PackedReplay.from_engine(g.eng, self.device) for g in self.groups]
+        torch.cuda.synchronize(self.device)  # the copies ran on the groups' streams
+        return PackedReplay.cat(parts).sort_by_episode_move()
+
     def examples(self, with_meta=False):
         """(planes [E, N+1, H, W], pi [E, A], value [E]) float32 device tensors of everything recorded so far, in the reference's
-        order: episode by episode, move by move (CoachBPP.py:80,133) -- the device buffer itself fills in completion order.
+        order -- the packed set expanded once (small pools, tests; training expands per minibatch instead).
         with_meta: also (episode ids [E] int64, move numbers [E] int32) as numpy arrays."""
-        out, eps, mvs = [], [], []
-        for g in self.groups:
-            n = _lib._i64(0)
-            g.eng._ck(g.eng.L.rp_examples_count(g.eng.h, _lib.C.byref(n)))
-            e = n.value
-            # allocated on the caller's stream; the engine fills them on the group's stream between two device syncs
-            planes = torch.empty((e, self.N + 1, self.H, self.W), dtype=torch.float32, device=self.device)
-            pi = torch.empty((e, self.A), dtype=torch.float32, device=self.device)
-            value = torch.empty((e,), dtype=torch.float32, device=self.device)
-            ep = np.empty(e, np.uint64); mv = np.empty(e, np.int32)
-            torch.cuda.synchronize(self.device)
-            if e:
-                g.eng._ck(g.eng.L.rp_examples_tensors(g.eng.h, 0, e, _lib.C.c_void_p(planes.data_ptr()), _lib.C.c_void_p(pi.data_ptr()),
-                                                      _lib.C.c_void_p(value.data_ptr())))
-                g.eng._ck(g.eng.L.rp_examples_meta(g.eng.h, 0, e, _lib._ptr(ep), _lib._ptr(mv)))
-            out.append((planes, pi, value))
-            eps.append(ep.astype(np.int64)); mvs.append(mv)
+        rep = self.examples_packed()
+        res = rep.dense()
         torch.cuda.synchronize(self.device)
-        ep, mv = np.concatenate(eps), np.concatenate(mvs)
-        order = np.lexsort((mv, ep))
-        idx = torch.as_tensor(order, device=self.device)
-        res = tuple(torch.cat([o[j] for o in out]).index_select(0, idx) for j in range(3))
-        return res + (ep[order], mv[order]) if with_meta else res
+        return res + (rep.episode.cpu().numpy(), rep.move.cpu().numpy()) if with_meta else res
 
     def clear_examples(self):
         for g in self.groups:

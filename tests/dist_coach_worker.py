@@ -25,7 +25,7 @@ def main(out_dir, world):
     W, H, N, salt = 10, 10, 8, 23
     args = dotdict(numMCTSSims=16, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=2, batch_size=8, numIters=1, numEps=7,
                    iterStepThreshold=5, binH_min=6, binH=10, numScoresForRank=20, numItersForTrainExamplesHistory=5, maxlenOfQueue=200000,
-                   numItems=N, checkpoint=os.path.join(out_dir, "ck_w%s_r%d" % (world, rank)), seed=3, use_graph=False, groups=1, tie_salt=salt,
+                   numItems=N, checkpoint=os.path.join(out_dir, "ck_w%s_r%d" % (world, rank)), seed=3, sample_seed=3000026, use_graph=False, groups=1, tie_salt=salt,
                    host_evaluator=host_evaluator(lambda s: "hashed", W * N, lambda s: salt))
     game = BinPackingGame(W, H, N, 1)
     torch.manual_seed(100 + rank)  # ranks start from different weights on purpose: learn()'s attach broadcasts rank 0's
@@ -36,7 +36,8 @@ def main(out_dir, world):
     gen = ItemsGenerator(W, H, N)
     coach = CoachBPP(game, nnet, gen.items_generator(100), W * H, gen, args, saved_rewards_list=[0.7, 0.8, 0.85, 0.9, 1.0])
     seeds = [11, 22, 33, 44, 55, 66, 77]
-    scores, (planes, pi, value) = coach.selfPlayIteration(1, draws=(9, seeds))  # sampled moves: the draw depends on (seed, episode, move) only
+    scores, replay = coach.selfPlayIteration(1, draws=(9, seeds))
+    planes, pi, value = replay.dense()  # sampled moves: the draw depends on (seed, episode, move) only
     # one full learn() iteration with pinned draws: self-play, R2 bookkeeping, data-parallel training from rank 0's seed
     coach.rewards_list = [0.7, 0.8, 0.85, 0.9, 1.0]
     coach.drawIteration = lambda: (8, [5, 6, 7, 8, 9, 10, 11])

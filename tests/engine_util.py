@@ -98,3 +98,37 @@ def planes_from_state(rows, rem, item_wh, W, H):
         if rem[i]:
             out[i + 1, :item_wh[i][1], :item_wh[i][0]] = 1.0
     return out
+
+
+def tree_digest(tree, N):
+    """SHA-256 over a whole search tree in tree_as_dict / OracleMCTS.dump format, covering exactly what assert_trees_equal
+    compares: per state (sorted by key) the key, Es and its kind; for live states the expanded flag; for expanded ones Ns and
+    every legal move's (action, P, Nsa) plus (Q, kind) of the visited ones.  Returns (hex digest of everything,
+    {level: (nodes, hex digest)}) -- level = items placed, so a mismatch can be localised without the other tree at hand.
+    A tree too large for the oracle to rebuild inside a GPU test (50x50 / 128 items / 800 sims: ~10^5 nodes, ~5 x 10^7 edges)
+    is pinned this way: the digest is generated once from the oracle and committed (tests/golden/make_c5_digest.py)."""
+    import hashlib
+    import struct
+    total = hashlib.sha256()
+    levels = {}
+    for key in sorted(tree):
+        rec = tree[key]
+        rem = np.frombuffer(key[1], np.uint8)
+        level = int(N - int((rem != 0).sum()))
+        parts = [key[0], key[1], struct.pack("<b", int(rec["es"]))]
+        if rec["es"] != 0:
+            parts.append(struct.pack("<B", int(rec["es_kind"])))
+        else:
+            parts.append(struct.pack("<B", int(rec["expanded"])))
+            if rec["expanded"]:
+                nsa = np.ascontiguousarray(rec["nsa"], np.uint32)
+                vis = nsa > 0
+                parts += [struct.pack("<I", int(rec["ns"])), np.ascontiguousarray(rec["actions"], np.int64).tobytes(),
+                          np.ascontiguousarray(rec["p"], np.float64).tobytes(), nsa.tobytes(),
+                          np.ascontiguousarray(np.asarray(rec["q"], np.float64)[vis]).tobytes(),
+                          np.ascontiguousarray(np.asarray(rec["q_kind"], np.uint8)[vis]).tobytes()]
+        lv = levels.setdefault(level, [0, hashlib.sha256()])
+        lv[0] += 1
+        for p in parts:
+            total.update(p); lv[1].update(p)
+    return total.hexdigest(), {k: (v[0], v[1].hexdigest()) for k, v in sorted(levels.items())}

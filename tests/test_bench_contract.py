@@ -110,3 +110,46 @@ def test_engine_hash_ignores_comments_but_not_code(tmp_path):
     assert src != a.read_text() and src != b.read_text()
     assert bench.engine_hash(str(a)) == bench.engine_hash()
     assert bench.engine_hash(str(b)) != bench.engine_hash()
+
+
+def _launcher_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RP_DIST_BACKEND"] = "gloo"
+    env.update(extra)
+    return env
+
+
+@pytest.mark.timeout(120)
+def test_a_dead_rank_ends_the_whole_launch_quickly():
+    """spawn_ranks polls all children: a rank that dies (here before the rendezvous, so the others block in it) makes the parent
+    stop the rest and return that rank's exit code within seconds, instead of waiting for the survivors until the driver's limit."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=_launcher_env(RP_BENCH_FAIL_RANK="2"),
+                       capture_output=True, text=True, timeout=100)
+    dt = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    assert dt < 10.0, "parent took %.1f s to give up on a dead rank" % dt
+    assert "dry_run" not in p.stdout  # no JSON line from a broken job
+
+
+def test_wait_ranks_kills_survivors_that_ignore_sigterm():
+    import time
+    sleeper = "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); time.sleep(60)"
+    procs = [subprocess.Popen([sys.executable, "-c", sleeper]), subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(7)"])]
+    t0 = time.time()
+    rc = bench.wait_ranks(procs, poll_s=0.05, grace_s=1.0)
+    assert rc == 7 and time.time() - t0 < 8.0
+    assert all(p.poll() is not None for p in procs)
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"]) for _ in range(3)]
+    assert bench.wait_ranks(ok, poll_s=0.05) == 0
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_dry_run_on_gloo():
+    """The driver's N = 8 launch shape, rehearsed on the CPU: eight ranks rendezvous on 127.0.0.1, agree through a MAX and a SUM
+    all-reduce and rank 0 prints one line with n_gpus = ranks_joined = 8."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env=_launcher_env(), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["ranks_joined"] == 8 and line["backend"] == "gloo" and line["requested"]["gpus"] == 8

@@ -26,10 +26,26 @@ def test_library_exports_every_declared_symbol():
     assert L.rp_version() == _lib.ABI_VERSION
 
 
-def test_config_struct_layout_matches_header():
+def test_config_struct_layout_matches_header(tmp_path):
+    """The ctypes mirror of rp_config against the C compiler's view of include/rp_engine.h: size and the offset of every field."""
+    import subprocess
     from resource_packing_self_play_amd import _lib
-    # int32 x6, double x2, int32 x6, uint64 x2, int32 x2, void*, int64
-    assert ctypes.sizeof(_lib.RpConfig) == 6 * 4 + 2 * 8 + 6 * 4 + 2 * 8 + 2 * 4 + 8 + 8
+    fields = [f[0] for f in _lib.RpConfig._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rp_engine.h"\nint main(void) {\n  printf("%zu\\n", sizeof(rp_config));\n'
+                   + "".join('  printf("%s %%zu\\n", offsetof(rp_config, %s));\n' % (f, f) for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    assert int(out[0]) == ctypes.sizeof(_lib.RpConfig)
+    for line in out[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(_lib.RpConfig, name).offset == int(off), name
+    # int32 x6, double x2, int32 x6, uint64 x2, int32 x2, void*, int64 x2
+    assert ctypes.sizeof(_lib.RpConfig) == 6 * 4 + 2 * 8 + 6 * 4 + 2 * 8 + 2 * 4 + 8 + 2 * 8
+    text = open(os.path.join(ROOT, "include", "rp_engine.h")).read()
+    assert int(re.search(r"#define RP_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION
 
 
 def test_engine_fails_loudly_without_gpu():

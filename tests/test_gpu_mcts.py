@@ -306,3 +306,38 @@ def test_reclaiming_dead_levels_changes_nothing():
     with pytest.raises(_lib.EngineError):
         run_until_idle(eng, host_evaluator(lambda s: "hashed", W * N, lambda s: 3))
     eng.close()
+
+
+@pytest.mark.timeout(1200)
+def test_c5_at_800_sims_matches_oracle_digest():
+    """BASELINE configs[4] at its OWN depth: 50x50 bin, 128 items, numMCTSSims = 800 per move (MCTS_bpp.py:37-38), one whole game with the
+    engine's DEFAULT node_cap (800 * 129 + 2) and arena sizing, sampled moves.  The oracle needs ~3 minutes and ~10 GB for this
+    game, so its answer is a committed fixture (tests/golden/make_c5_digest.py, generated with the pinned C oracle in the build
+    container): number of moves, outcome, score, the oracle's counters, the node count, and SHA-256 digests -- of the whole tree and
+    per level -- over every node's (key, Es, Ns) and every legal move's (action, P, Nsa, Q, kind)."""
+    import json
+    from engine_util import tree_digest
+    from resource_packing_self_play_amd import _lib
+    f = json.load(open(os.path.join(GOLDEN, "mcts_c5_800_digest.json")))
+    W, H, N, sims, A = f["W"], f["H"], f["N"], f["sims"], f["W"] * f["N"]
+    assert (W, H, N, sims) == (50, 50, 128, 800)
+    wh = np.array(f["item_wh"], np.uint8)
+    eng = make_engine(W, H, N, 1, sims, cpuct=f["cpuct"], alpha=f["alpha"], move_rule=_lib.MOVE_SAMPLE, seed=f["seed"], tie_salt=f["salt"])
+    eng.set_step_cap(16)
+    eng.set_rank_buffer(np.array(f["buf"]))
+    eng.begin_episodes(wh[None], [W * H], episode_id=[f["episode_id"]])
+    run_until_idle(eng, host_evaluator(lambda s: f["kind"], A, lambda s: f["salt"]))
+    ids, outcome, score, moves = eng.pop_finished()
+    assert (int(ids[0]), int(outcome[0]), float(score[0]), int(moves[0])) == (f["episode_id"], f["outcome"], f["score"], len(f["actions"]))
+    c, st = eng.counters(), f["stats"]
+    assert c["simulations"] == st["searches"] and c["expansions"] == st["expansions"] and c["terminal_returns"] == st["terminal_returns"]
+    assert c["path_edges"] == st["path_edges"] and c["sum_valid_select"] == st["sum_valid_select"] and c["sum_valid_leaf"] == st["sum_valid_leaf"]
+    assert c["nodes"] == st["nodes"] == f["n_nodes"] and c["transposition_links"] == st["transposition_hits"]
+    tree = tree_as_dict(eng.dump_tree(0))
+    assert len(tree) == f["n_nodes"]
+    digest, levels = tree_digest(tree, N)
+    bad = [lv for lv, (cnt, dg) in levels.items() if [cnt, dg] != f["levels"].get(str(lv))]
+    assert not bad and len(levels) == len(f["levels"]), "levels (items placed) whose nodes differ from the oracle's: %s" % bad[:10]
+    assert digest == f["tree_sha256"]
+    print("c5 at 800 sims: %d nodes, %d moves, arena peak %s" % (len(tree), int(moves[0]), eng.arena_peak()))
+    eng.close()

@@ -3,6 +3,7 @@ imported Python reference (tests/golden/make_golden.py).  Bit-exact everywhere."
 import glob
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -139,3 +140,33 @@ def test_mcts_fixtures_cover_the_hard_cases():
         n += 1
     assert n >= 8
     assert kinds[1] > 0 and strong > 0
+
+
+def test_c5_digest_fixtures_are_what_the_oracle_plays():
+    """tests/golden/mcts_c5_800_digest.json pins the engine at 50x50 / 128 items / 800 sims on the GPU (the oracle needs minutes for that
+    game); here the SAME generator is re-run at 20 sims per move and must reproduce its committed small fixture bit for bit, which
+    pins the digest function and the generator's instance; the large fixture is checked for shape and for the shared instance."""
+    import json
+    sys.path.insert(0, GOLDEN)
+    import make_c5_digest as gen
+    from engine_util import tree_digest
+    small = json.load(open(os.path.join(GOLDEN, "mcts_c5_20_digest.json")))
+    big = json.load(open(os.path.join(GOLDEN, "mcts_c5_800_digest.json")))
+    W, H, N, A = gen.W, gen.H, gen.N, gen.W * gen.N
+    rng = np.random.default_rng(2020 + 20)
+    wh = gen.gen_items(rng, W, H, N)
+    buf = rng.uniform(0.8, 1.0, 100)
+    assert wh.tolist() == small["item_wh"] and buf.tolist() == small["buf"]
+    m = orc.OracleMCTS(W, H, N, 1.0, 0.75, lambda b, r: ev.table_eval(gen.KIND, ev.pack_board(b), r, A, gen.SALT),
+                       lambda b, r: ev.tie_value(ev.pack_board(b), r, gen.SALT))
+    m.begin_episode(wh[:, 0], wh[:, 1], W * H, buf)
+    actions, _, outcome, score = m.play_episode(20, policy=1, seed=gen.SEED, episode_id=gen.EPISODE, want_counts=False)
+    assert [int(a) for a in actions] == small["actions"] and (outcome, score) == (small["outcome"], small["score"])
+    assert m.stats() == small["stats"]
+    digest, levels = tree_digest(m.dump(), N)
+    assert digest == small["tree_sha256"] and {str(k): [v[0], v[1]] for k, v in levels.items()} == small["levels"]
+    m.close()
+    assert (big["W"], big["H"], big["N"], big["sims"]) == (50, 50, 128, 800) and big["stats"]["searches"] == 800 * len(big["actions"])
+    assert big["n_nodes"] == big["stats"]["nodes"] == sum(v[0] for v in big["levels"].values()) and len(big["tree_sha256"]) == 64
+    rng = np.random.default_rng(2020 + 800)
+    assert gen.gen_items(rng, W, H, N).tolist() == big["item_wh"] and rng.uniform(0.8, 1.0, 100).tolist() == big["buf"]
