@@ -289,9 +289,13 @@ int rp_examples_packed(rp_ctx *ctx, int64_t n_examples, int64_t n_sparse, uint32
  * :43): row k of the outputs = example index_dev[k] (NULL: example k) of the caller-owned packed arrays above (sp_off 64-bit here: sets
  * gathered from several ranks and iterations outgrow 32 bits), expanded exactly like rp_examples_tensors.  Stateless: uses only the
  * context's geometry and stream. */
-int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, const uint32_t *key_dev, const uint8_t *item_wh_dev, const int32_t *value_dev,
-                       const int64_t *sp_off_dev, const int32_t *sp_n_dev, const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev,
-                       float *pi_dev, float *value_out_dev);
+int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, int64_t n_examples /* E */, int64_t n_sparse /* S */, const uint32_t *key_dev,
+                       const uint8_t *item_wh_dev, const int32_t *value_dev, const int64_t *sp_off_dev, const int32_t *sp_n_dev,
+                       const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev, float *pi_dev, float *value_out_dev);
+/* Every index is checked on the device against E and S (an index list or a pool entry outside the arrays yields a zero row, never a
+ * stray access); rp_check synchronises the context's stream and returns the first error device code recorded since the last check
+ * (RP_ERR_ARG for such an index, RP_ERR_CAPACITY for an arena overflow), like every synchronising call does. */
+int rp_check(rp_ctx *ctx);
 
 /* ---- inspection (parity tests) --------------------------------------------------------- */
 /* Sizes of slot g's tree: nodes in use and the span of its legal-move arena (the index range of rp_dump_tree's edge arrays). */

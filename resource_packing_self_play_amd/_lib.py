@@ -89,7 +89,8 @@ _SIGS = {
     "rp_examples_clear": (C.c_int, [_vp]),
     "rp_examples_packed_count": (C.c_int, [_vp, _vp, _vp]),
     "rp_examples_packed": (C.c_int, [_vp, _i64, _i64] + [_vp] * 9),
-    "rp_expand_examples": (C.c_int, [_vp, _i64] + [_vp] * 11),
+    "rp_expand_examples": (C.c_int, [_vp, _i64, _vp, _i64, _i64] + [_vp] * 10),
+    "rp_check": (C.c_int, [_vp]),
     "rp_leaf_count_async": (C.c_int, [_vp, _vp]),
     "rp_tree_size": (C.c_int, [_vp, _i32, _vp, _vp]),
     "rp_arena_peak": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -407,8 +408,12 @@ class Engine:
         """rp_expand_examples on torch tensors (all on this context's device; index int64 or None)."""
         n = planes.shape[0]
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
-        self._ck(self.L.rp_expand_examples(self.h, n, ptr(index), ptr(key), ptr(wh), ptr(value), ptr(sp_off), ptr(sp_n), ptr(sp_act), ptr(sp_cnt),
-                                           ptr(planes), ptr(pi), ptr(value_out)))
+        self._ck(self.L.rp_expand_examples(self.h, n, ptr(index), int(key.shape[0]), int(sp_act.shape[0]), ptr(key), ptr(wh), ptr(value), ptr(sp_off),
+                                           ptr(sp_n), ptr(sp_act), ptr(sp_cnt), ptr(planes), ptr(pi), ptr(value_out)))
+
+    def check(self):
+        """Synchronises the context's stream and raises if a kernel recorded a device error since the last check."""
+        self._ck(self.L.rp_check(self.h))
 
     def leaf_states(self, max_rows=None):
         max_rows = self.G if max_rows is None else max_rows

@@ -92,7 +92,9 @@ class NNetWrapper(NeuralNet):
     def train_packed(self, replay):
         """Training on a PackedReplay (replay.py): every minibatch is expanded to planes / pi / value by the engine's kernel
         (rp_expand_examples) right before its forward pass, so the replay set stays at ~0.4 KB per example instead of 55 KB."""
-        return self._train_loop(len(replay), replay.expand, replay.device)
+        hist = self._train_loop(len(replay), replay.expand, replay.device)
+        replay.check()  # an index outside the packed arrays is reported by the expand kernel, not silently zero-filled
+        return hist
 
     def _train_loop(self, n, fetch, device):
         """Same schedule as the reference: a fresh Adam with default hyper-parameters (`args.lr` is never read there,

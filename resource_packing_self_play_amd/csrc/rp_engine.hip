@@ -48,7 +48,7 @@ typedef unsigned char u8;
 
 enum { CNT_SIMS = 0, CNT_EXPAND, CNT_TERMINAL, CNT_PATH, CNT_NVALID_SEL, CNT_NVALID_LEAF, CNT_TRANSPOSE, CNT_NODES,
        CNT_MOVES, CNT_EPISODES, CNT_PROBES, CNT_KEYBYTES, CNT_VIS_SEL, CNT_VIS_NEW, CNT_RES0, CNT_RES1, CNT_N };
-enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7, ERR_VIS_CAP = 8 };
+enum { ERR_NODE_CAP = 1, ERR_EDGE_CAP = 2, ERR_TABLE_FULL = 3, ERR_BAD_ACTION = 4, ERR_PATH = 5, ERR_FINISHED_CAP = 6, ERR_EXAMPLES_CAP = 7, ERR_VIS_CAP = 8, ERR_BAD_EXAMPLE = 9 };
 
 struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
     u32 ns;         // Ns[s]          (MCTS_bpp.py:103,138)
@@ -278,19 +278,21 @@ struct ValidSink {  // where gen_valid_moves puts its result
 // item's actions i * W + j in ascending order.  The previous form tested every (item, column) pair against all H rows:
 // ~5 H instructions per 64 actions, 1 100 per node at 20x20/32 and 25 000 at 50x50/128.
 // Returns the number of legal moves, or -1 if they do not fit sink.cap.  Must be called by all 64 lanes.
-template <typename row_t>
+// BIG = false: the instance for N <= 64 -- the second item word and everything derived from it folds away.
+template <typename row_t, bool BIG = true>
 __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0, u64 rem1, const ValidSink &sink) {
     const int lane = lane_id(), W = p.W, H = p.H, N = p.N;
+    const bool big = BIG && N > 64;
     const row_t full = (row_t)full_mask(W);
     int w_lo = sink.w_lo, h_lo = sink.h_lo, w_hi = sink.w_hi, h_hi = sink.h_hi;
-    const bool un_lo = lane < N && ((rem0 >> lane) & 1ull), un_hi = lane + 64 < N && ((rem1 >> lane) & 1ull);  // plane sum != 0 (BinPackingGame.py:86)
+    const bool un_lo = lane < N && ((rem0 >> lane) & 1ull), un_hi = big && lane + 64 < N && ((rem1 >> lane) & 1ull);  // plane sum != 0 (BinPackingGame.py:86)
     if (!sink.have_sizes) {
         w_lo = h_lo = w_hi = h_hi = 0;
         if (lane < N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
-        if (lane + 64 < N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+        if (big && lane + 64 < N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
     }
     sink.vm[lane] = 0ull;
-    if (N > 64) sink.vm[64 + lane] = 0ull;
+    if (big) sink.vm[64 + lane] = 0ull;
     // occupied cells per column (lane c <-> column c), inclusive prefix sum I and its left neighbour
     int I = 0;
     for (int r = 0; r < H; ++r) {
@@ -303,7 +305,7 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
     row_t E = E1;
     for (int w = 1; w <= W; ++w) {
         if (w > 1) E = E & (row_t)(E1 >> (w - 1));  // bit j: the window [j, j + w) of this lane's row is empty (and fits: E1 has no bits >= W)
-        const u64 im0 = __ballot(un_lo && w_lo == w), im1 = N > 64 ? __ballot(un_hi && w_hi == w) : 0ull;
+        const u64 im0 = __ballot(un_lo && w_lo == w), im1 = big ? __ballot(un_hi && w_hi == w) : 0ull;
         if ((im0 | im1) == 0ull) continue;  // no unplaced item of this width
         const row_t X = wave_scan_or(E);                      // inclusive prefix-OR over the rows
         const row_t Xex = wave_shift_up1(X);
@@ -326,11 +328,11 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
     }
     wave_sync();
     // lanes = items: counts, offsets, actions in ascending order
-    u64 m_lo = sink.vm[lane], m_hi = N > 64 ? sink.vm[64 + lane] : 0ull;
+    u64 m_lo = sink.vm[lane], m_hi = big ? sink.vm[64 + lane] : 0ull;
     int inc_lo = __popcll(m_lo), inc_hi = __popcll(m_hi);
     const int c_lo = inc_lo, c_hi = inc_hi;
     inc_lo = (int)wave_scan_add((u32)inc_lo);
-    if (N > 64) inc_hi = (int)wave_scan_add((u32)inc_hi);
+    if (big) inc_hi = (int)wave_scan_add((u32)inc_hi);
     const int tot_lo = __builtin_amdgcn_readlane(inc_lo, 63), nv = tot_lo + __builtin_amdgcn_readlane(inc_hi, 63);
     if (sink.mask)
         for (int a = lane; a < p.A; a += 64) sink.mask[a] = 0;
@@ -488,7 +490,7 @@ template <typename T> __device__ __host__ __forceinline__ T *slot_region(const D
 // ------------------------------------------------------------------------------------------------
 // slot-local tree
 // ------------------------------------------------------------------------------------------------
-template <typename row_t> struct Tree {
+template <typename row_t, bool BIG = true> struct Tree {
     const DP &p;
     int g;
     NodeHdr *hdr;
@@ -502,7 +504,8 @@ template <typename row_t> struct Tree {
     const u8 *wh;
     Arena pa, va;  // legal-move runs, visited blocks
     u32 n_nodes;
-    u64 c_probes, c_keybytes, c_nodes;
+    u32 cnt = 0;   // per-launch event counts: LANE k holds counter k (one VGPR; sixteen wave-uniform counters took sixteen SGPRs of a
+                   // kernel that already spills scalar registers) -- count() adds, add_counters() flushes
     u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
     u64 *vm;       // this wave's LDS scratch for gen_valid_moves ([VM_WORDS]), with `stage`
     int have_sizes = 0, w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;  // the slot's item sizes in lanes (load_sizes), constant over an episode
@@ -522,7 +525,13 @@ template <typename row_t> struct Tree {
         va.chunk = p.vchunk; va.n_chunks = p.n_vchunks;
         va.cur = p.va_cur + lv; va.head = p.va_head + lv; va.used = p.va_used + lv;
         va.next = p.va_next + (size_t)g * p.n_vchunks; va.stack = p.va_stack + (size_t)g * p.n_vchunks; va.tf = p.va_tf + (size_t)g * 2;
-        c_probes = c_keybytes = c_nodes = 0;
+    }
+    __device__ __forceinline__ void count(int k, u32 v = 1u) { cnt += lane_id() == k ? v : 0u; }
+    // one coalesced read-modify-write of the slot's sixteen 64-bit totals (plain stores: the slot's own wave is their only writer)
+    __device__ void flush_counters() {
+        const int lane = lane_id();
+        if (lane < CNT_N && cnt) p.slot_cnt[(size_t)g * CNT_N + lane] += (u64)cnt;
+        cnt = 0;
     }
     __device__ void store_sizes() {
         if (lane_id() == 0) p.n_nodes[g] = n_nodes;
@@ -531,7 +540,7 @@ template <typename row_t> struct Tree {
     __device__ void load_sizes() {
         const int lane = lane_id();
         if (lane < p.N) { w_lo = wh[2 * lane]; h_lo = wh[2 * lane + 1]; }
-        if (lane + 64 < p.N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
+        if (BIG && lane + 64 < p.N) { w_hi = wh[2 * (lane + 64)]; h_hi = wh[2 * (lane + 64) + 1]; }
         have_sizes = 1;
     }
     __device__ void reset_arenas() {
@@ -550,8 +559,33 @@ template <typename row_t> struct Tree {
     }
     static __device__ __forceinline__ int level_of(int N, u64 rem0, u64 rem1) { return N - __popcll(rem0) - __popcll(rem1); }
 
-    // key of a node -> lane-resident rows + uniform remaining words
+    // key of a node -> lane-resident rows + uniform remaining words.  The key is H rows followed by the remaining-item words, so ONE
+    // load -- lane l takes key element l -- brings all of it when H + words <= 64 (packed() below); fetch_key only requests it, so a
+    // caller can ask for a node's key together with its header and decode it a round trip later, if at all (resolve_child).
+    static constexpr int KEY_PER_ROW = sizeof(row_t) / 4;
+    __device__ __forceinline__ bool packed() const { return p.H + (p.RMW + KEY_PER_ROW - 1) / KEY_PER_ROW <= 64; }
+    __device__ __forceinline__ row_t fetch_key(u32 node) const {
+        const row_t *k = (const row_t *)(key + (size_t)node * p.KW);
+        const int n = p.H + (p.RMW + KEY_PER_ROW - 1) / KEY_PER_ROW;
+        return lane_id() < n ? k[lane_id()] : (row_t)0;
+    }
+    __device__ __forceinline__ void decode_key(row_t kv, row_t &myrow, u64 &rem0, u64 &rem1) const {
+        myrow = lane_id() < p.H ? kv : (row_t)0;
+        if (KEY_PER_ROW == 2) {
+            rem0 = (u64)RowOps<row_t>::at(kv, p.H);
+            if (p.RMW < 2) rem0 &= 0xFFFFFFFFull;  // an odd word count leaves a padding word behind the last one
+            rem1 = BIG && p.RMW > 2 ? (u64)RowOps<row_t>::at(kv, p.H + 1) : 0ull;
+            if (BIG && p.RMW == 3) rem1 &= 0xFFFFFFFFull;
+        } else {
+            rem0 = (u64)(u32)RowOps<row_t>::at(kv, p.H);
+            if (p.RMW > 1) rem0 |= (u64)(u32)RowOps<row_t>::at(kv, p.H + 1) << 32;
+            rem1 = 0;
+            if (BIG && p.RMW > 2) rem1 = (u64)(u32)RowOps<row_t>::at(kv, p.H + 2);
+            if (BIG && p.RMW > 3) rem1 |= (u64)(u32)RowOps<row_t>::at(kv, p.H + 3) << 32;
+        }
+    }
     __device__ void load_key(u32 node, row_t &myrow, u64 &rem0, u64 &rem1) const {
+        if (packed()) { decode_key(fetch_key(node), myrow, rem0, rem1); return; }
         const u32 *k = key + (size_t)node * p.KW;
         myrow = 0;
         if (lane_id() < p.H) myrow = ((const row_t *)k)[lane_id()];
@@ -572,7 +606,7 @@ template <typename row_t> struct Tree {
     __device__ bool key_equals(u32 node, row_t myrow, u64 rem0, u64 rem1) {
         row_t r2; u64 a0, a1;
         load_key(node, r2, a0, a1);
-        c_keybytes += (u64)p.KW * 4;
+        count(CNT_KEYBYTES, (u32)p.KW * 4u);
         return __all((r2 == myrow) && (a0 == rem0) && (a1 == rem1)) != 0;
     }
     __device__ u64 hash_state(row_t myrow, u64 rem0, u64 rem1) const {
@@ -581,25 +615,28 @@ template <typename row_t> struct Tree {
         h ^= mix64(rem0 ^ 0xD1B54A32D192ED03ull) ^ mix64(rem1 + 0x8CB92BA72F3D8DD7ull);
         return mix64(h);
     }
-    // s in self.Es ?  -- 64 table slots per probe; returns node id or NONE32 (+ the slot to insert at)
+    // s in self.Es ?  Open addressing over ALIGNED buckets of 16 slots = one 128-byte line per probe (lanes 16-63 repeat the addresses of
+    // lanes 0-15: the same request); at the table's load of <= 1/2 a bucket without an empty slot is a ~1e-3 event, so a lookup is
+    // one line where the 64-slot window took four.  A key lives in the first bucket from its home that had room when it was inserted;
+    // nothing is ever deleted, so the first empty slot ends the search.  Returns node id or NONE32 (+ the slot to insert at).
     __device__ u32 find(row_t myrow, u64 rem0, u64 rem1, u64 h, u32 &insert_slot) {
         const u32 mask = (u32)p.table_cap - 1u, tag = (u32)(h >> 32);
-        u32 slot = (u32)h & mask;
-        for (int it = 0; it <= p.table_cap / 64; ++it) {
-            u64 e = table[(slot + lane_id()) & mask];
-            c_probes++;
-            u64 empty = __ballot(e == 0ull);
-            u64 hit = __ballot(e != 0ull && (u32)(e >> 32) == tag);
-            int first_empty = empty ? __ffsll((long long)empty) - 1 : 64;
-            u64 cand = hit & (first_empty >= 64 ? ~0ull : ((1ull << first_empty) - 1ull));
+        u32 slot = (u32)h & mask & ~15u;
+        for (int it = 0; it <= p.table_cap / 16; ++it) {
+            u64 e = table[slot + (lane_id() & 15)];
+            count(CNT_PROBES);
+            u64 empty = __ballot(e == 0ull) & 0xFFFFull;
+            u64 hit = __ballot(e != 0ull && (u32)(e >> 32) == tag) & 0xFFFFull;
+            int first_empty = empty ? __ffsll((long long)empty) - 1 : 16;
+            u64 cand = hit & ((1ull << first_empty) - 1ull);
             while (cand) {
                 int l = __ffsll((long long)cand) - 1;
                 cand &= cand - 1;
                 u32 id = (u32)__builtin_amdgcn_readlane((int)(u32)e, l) - 1u;
                 if (key_equals(id, myrow, rem0, rem1)) return id;
             }
-            if (first_empty < 64) { insert_slot = (slot + first_empty) & mask; return NONE32; }
-            slot = (slot + 64) & mask;
+            if (first_empty < 16) { insert_slot = slot + first_empty; return NONE32; }
+            slot = (slot + 16) & mask;
         }
         if (lane_id() == 0) set_error(p, ERR_TABLE_FULL);
         insert_slot = NONE32;
@@ -623,7 +660,7 @@ template <typename row_t> struct Tree {
         ValidSink sink;
         sink.act = stage; sink.mask = nullptr; sink.cap = p.A; sink.vm = vm;
         sink.have_sizes = have_sizes; sink.w_lo = w_lo; sink.h_lo = h_lo; sink.w_hi = w_hi; sink.h_hi = h_hi;
-        const int nv = gen_valid_moves<row_t>(p, wh, myrow, rem0, rem1, sink);
+        const int nv = gen_valid_moves<row_t, BIG>(p, wh, myrow, rem0, rem1, sink);
         wave_sync();
         u32 room, off = 0;
         if (nv > 0) {
@@ -649,7 +686,7 @@ template <typename row_t> struct Tree {
             table[insert_slot] = ((u64)(u32)(h >> 32) << 32) | (u64)(id + 1u);
         }
         n_nodes++;
-        c_nodes++;
+        count(CNT_NODES);
         return id;
     }
     __device__ u32 find_or_materialize(row_t myrow, u64 rem0, u64 rem1, bool *was_new) {
@@ -661,16 +698,20 @@ template <typename row_t> struct Tree {
         return id;
     }
     // child state of (node, action): BinPackingGame.getNextState (BinPackingGame.py:58-76); links visited entry e to it
-    __device__ u32 resolve_child(u32 node, u32 e, int a, bool *was_new) {
+    // kv: the parent's key as fetch_key returned it (have_kv), else it is loaded here
+    __device__ u32 resolve_child(u32 node, u32 e, int a, bool *was_new, bool have_kv = false, row_t kv = 0) {
         row_t myrow; u64 rem0, rem1;
-        load_key(node, myrow, rem0, rem1);
+        if (have_kv) decode_key(kv, myrow, rem0, rem1); else load_key(node, myrow, rem0, rem1);
         a = uni(a);
         int i = (int)(((u32)a * p.magicW) >> 20), j = a - i * p.W;
         int iw, ih;  // the item's size: from the lanes when the kernel loaded the slot's sizes, else one dependent read
-        if (have_sizes) { iw = i < 64 ? __builtin_amdgcn_readlane(w_lo, i) : __builtin_amdgcn_readlane(w_hi, i - 64); ih = i < 64 ? __builtin_amdgcn_readlane(h_lo, i) : __builtin_amdgcn_readlane(h_hi, i - 64); }
+        if (have_sizes) {
+            iw = (!BIG || i < 64) ? __builtin_amdgcn_readlane(w_lo, i & 63) : __builtin_amdgcn_readlane(w_hi, i - 64);
+            ih = (!BIG || i < 64) ? __builtin_amdgcn_readlane(h_lo, i & 63) : __builtin_amdgcn_readlane(h_hi, i - 64);
+        }
         else { iw = uni((int)wh[2 * i]); ih = uni((int)wh[2 * i + 1]); }
         myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, iw, ih);
-        if (i < 64) rem0 &= ~(1ull << i); else rem1 &= ~(1ull << (i - 64));
+        if (!BIG || i < 64) rem0 &= ~(1ull << (i & 63)); else rem1 &= ~(1ull << (i - 64));
         u32 child = find_or_materialize(myrow, rem0, rem1, was_new);
         if (lane_id() == 0 && child != NONE32 && e != NONE32) vChild[e] = child;
         return child;
@@ -803,23 +844,12 @@ template <typename row_t> struct Tree {
     }
 };
 
-// Per-slot event counts: lane k adds counter k -- one coalesced read-modify-write instead of lane 0 walking the sixteen counters one
-// dependent memory round trip after the other (that walk was a fifth of k_search's wait cycles).
-template <typename T> __device__ void add_counters(const DP &p, int g, const T *c) {
-    const int lane = lane_id();
-    u64 mine = 0;
-#pragma unroll
-    for (int k = 0; k < CNT_N; ++k)
-        if (lane == k) mine = (u64)c[k];
-    if (lane < CNT_N && mine) p.slot_cnt[(size_t)g * CNT_N + lane] += mine;
-}
-
 __device__ u64 sample_u64(u64 seed, u64 episode, u64 move) { return mix64(mix64(mix64(seed) ^ episode) ^ move); }
 
 // CoachBPP.executeEpisode's move (CoachBPP.py:86-99) for one slot whose search budget is spent.
 // action < 0: pick by p.move_rule.  Leaves phase RUNNING, EPISODE_DONE or FAILED.
-template <typename row_t, typename CT>
-__device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, int action, CT *c) {
+template <typename row_t, bool BIG>
+__device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &root, int action) {
     root = uni(root);
     NodeHdr hd = t.load_hdr(root);
     const int lane = lane_id();
@@ -919,7 +949,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
         arena_free_level(t.va, hd.depth);
     }
     root = child;
-    c[CNT_MOVES]++;
+    t.count(CNT_MOVES);
     NodeHdr ch = t.hdr[child];
     int moves = p.moves[g] + 1;
     if (lane == 0) { p.root[g] = root; p.moves[g] = moves; p.sims_done[g] = 0; }
@@ -928,7 +958,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
         t.load_key(child, myrow, rem0, rem1);
         double r;
         ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
-        c[CNT_EPISODES]++;
+        t.count(CNT_EPISODES);
         if (p.max_examples > 0)  // return [(x[0], x[1], r) for x in trainExamples] (CoachBPP.py:99)
             for (int q = lane; q < moves && q < p.N; q += 64) {
                 u32 idx = p.slot_ex[(size_t)g * p.N + q];
@@ -954,8 +984,8 @@ __device__ void play_move_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, in
 
 // A slot whose episode ended takes the next instance of the pool (CoachBPP.py:123-134: the next self-play
 // episode, a new MCTS with an empty tree).  Leaves the slot RUNNING at the new root, or IDLE when the pool is used up.
-template <typename row_t, typename CT>
-__device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root, CT *c) {
+template <typename row_t, bool BIG>
+__device__ void restart_slot_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &root) {
     const int lane = lane_id();
     unsigned long long idx = 0;
     if (lane == 0) idx = atomicAdd(p.next_instance, 1ull);
@@ -984,7 +1014,6 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
     root = t.find_or_materialize(myrow, rem0, rem1, &was_new);
     wave_sync();
     if (lane == 0) { p.root[g] = root; p.phase[g] = root == NONE32 ? RP_PHASE_FAILED : RP_PHASE_RUNNING; }
-    (void)c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -995,7 +1024,7 @@ __device__ void restart_slot_impl(const DP &p, Tree<row_t> &t, int g, u32 &root,
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 5
 #endif
-template <typename row_t>
+template <typename row_t, bool BIG>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(DP p) {
     __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     extern __shared__ u16 s_stage[];  // [WAVES_PER_BLOCK][A]
@@ -1007,12 +1036,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
+    Tree<row_t, BIG> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
     t.load_sizes();
     phase = uni(phase); root = uni(root); sims_done = uni(sims_done); t.n_nodes = uni(t.n_nodes);
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
-    u32 c[CNT_N];  // per-launch event counts (uniform across the wave)
-    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
+    const bool key_ahead = t.packed();  // a node's key can ride along with its header (one load instruction)
     int launched = 0;
     for (;;) {
         // A slot near the end of its game runs many evaluator-free simulations (terminal hits); the cap bounds the
@@ -1029,9 +1057,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
         u32 vkind = RP_KIND_WEAK;
         bool need_eval = false, failed = false;
         for (;;) {
+            // the node's key is requested WITH its header: if the chosen edge has no child yet (four simulations in five end that way)
+            // the child state is built from it without another dependent round trip; otherwise the 84 bytes were a wasted line
+            row_t kv = 0;
+            if (key_ahead) kv = t.fetch_key(node);
             NodeHdr hd = t.load_hdr(node);
             if (hd.term != 0) {  // :81-83
-                v = (double)hd.term; vkind = hdr_term_kind(hd); c[CNT_TERMINAL]++;
+                v = (double)hd.term; vkind = hdr_term_kind(hd); t.count(CNT_TERMINAL);
                 break;
             }
             if (!(hd.flags & HF_EXPANDED)) { need_eval = true; break; }  // :85 leaf
@@ -1039,17 +1071,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
             int act_sel;
             const u32 vis_before = hd.vis_n;
             u32 e = t.select_edge(node, hd, vmask, ksel, child, act_sel);
-            c[CNT_VIS_NEW] += hd.vis_n - vis_before;
+            t.count(CNT_VIS_NEW, hd.vis_n - vis_before);
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
-            if (depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
+            if (!BIG || depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
             else if (lane == depth - 64) { pe1 = e; pn1 = node; }
             depth++;
-            c[CNT_PATH]++; c[CNT_NVALID_SEL] += hd.n_valid; c[CNT_VIS_SEL] += vis_before;
+            t.count(CNT_PATH); t.count(CNT_NVALID_SEL, hd.n_valid); t.count(CNT_VIS_SEL, vis_before);
             if (child == NONE32) {  // first traversal of this edge: build the state, look it up (:125-128,:76)
                 bool was_new;
-                child = t.resolve_child(node, e, act_sel >= 0 ? act_sel : (int)t.pAct[hd.prior_off + ksel], &was_new);
+                child = t.resolve_child(node, e, act_sel >= 0 ? act_sel : (int)t.pAct[hd.prior_off + ksel], &was_new, key_ahead, kv);
                 if (child == NONE32) { failed = true; break; }
-                if (!was_new) c[CNT_TRANSPOSE]++;
+                if (!was_new) t.count(CNT_TRANSPOSE);
                 wave_sync();
             }
             node = child;
@@ -1062,7 +1094,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
         if (need_eval) {  // hand the leaf to the evaluator (nnet.predict, :87); commit kernel finishes the simulation
             u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
             if (lane < depth) { pe[lane] = pe0; pn[lane] = pn0; }
-            if (lane + 64 < depth) { pe[lane + 64] = pe1; pn[lane + 64] = pn1; }
+            if (BIG && lane + 64 < depth) { pe[lane + 64] = pe1; pn[lane + 64] = pn1; }
             if (lane == 0) {
                 p.leaf_node[g] = node;
                 p.path_len[g] = depth;
@@ -1071,17 +1103,16 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
             break;
         }
         if (lane < depth) t.backup_entry(pn0, pe0, v, vkind);
-        if (lane + 64 < depth) t.backup_entry(pn1, pe1, v, vkind);
+        if (BIG && lane + 64 < depth) t.backup_entry(pn1, pe1, v, vkind);
         if (lane == 0) { p.last_v[g] = v; p.last_vkind[g] = (int)vkind; }
         sims_done++;
         launched++;
-        c[CNT_SIMS]++;
+        t.count(CNT_SIMS);
         wave_sync();
     }
     t.store_sizes();
-    c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
     if (lane == 0) { p.phase[g] = phase; p.sims_done[g] = sims_done; }
-    add_counters(p, g, c);
+    t.flush_counters();
 }
 
 // CoachBPP.executeEpisode's move for every slot whose search budget is spent (RP_MOVE_ARGMAX_FIRST / RP_MOVE_SAMPLE), and the
@@ -1095,18 +1126,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
-    u32 c[CNT_N];
-    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
     u32 root = p.root[g];
-    play_move_impl<row_t>(p, t, g, root, -1, c);
+    play_move_impl<row_t>(p, t, g, root, -1);
     wave_sync();
     if (p.phase[g] == RP_PHASE_EPISODE_DONE && p.auto_restart) {
-        restart_slot_impl<row_t>(p, t, g, root, c);
+        restart_slot_impl<row_t>(p, t, g, root);
         wave_sync();
     }
     t.store_sizes();
-    c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes; c[CNT_NODES] = t.c_nodes;
-    add_counters(p, g, c);
+    t.flush_counters();
 }
 
 // np.sum(Ps[s]) over the dense A-vector in NumPy's pairwise order (MCTS_bpp.py:90,100).  mode 0:
@@ -1553,10 +1581,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_set_roots(DP p, int fi
     bool was_new;
     u32 id = t.find_or_materialize(myrow, rem0, rem1, &was_new);
     t.store_sizes();
-    u64 c[CNT_N];
-    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
-    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, g, c);
+    t.flush_counters();
     if (lane == 0) {
         p.root[g] = id;
         p.sims_done[g] = 0;
@@ -1574,13 +1599,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
-    u64 c[CNT_N];
-    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = p.root[g];
-    play_move_impl<row_t>(p, t, g, root, action[k], c);
+    play_move_impl<row_t>(p, t, g, root, action[k]);
     t.store_sizes();
-    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, g, c);
+    t.flush_counters();
 }
 
 // counts[a] = Nsa[(root, a)] (MCTS_bpp.py:40-41)
@@ -1607,13 +1629,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_pool_begin(DP p) {
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
     Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
-    u64 c[CNT_N];
-    for (int q = 0; q < CNT_N; ++q) c[q] = 0;
     u32 root = NONE32;
-    restart_slot_impl<row_t>(p, t, g, root, c);
+    restart_slot_impl<row_t>(p, t, g, root);
     t.store_sizes();
-    c[CNT_NODES] = t.c_nodes; c[CNT_PROBES] = t.c_probes; c[CNT_KEYBYTES] = t.c_keybytes;
-    add_counters(p, g, c);
+    t.flush_counters();
 }
 
 // Training tensors of replay examples: planes as getBinItem (BinPackingGame.py:118-120), pi = counts / sum in float64 rounded to
@@ -1630,6 +1649,7 @@ struct PackedEx {
     const int *sp_n;     // [E]
     const u16 *sp_act;   // pool
     const u32 *sp_cnt;
+    long long n_examples, n_sparse;  // sizes of the arrays: every index is checked against them (caller-owned data)
 };
 template <typename row_t>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, PackedEx ex, long long first, long long count, const long long *index, float *planes,
@@ -1638,6 +1658,22 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, PackedE
     if (k >= count) return;
     const long long idx = index ? index[k] : first + k;
     const int lane = lane_id();
+    float *row = pi + (size_t)k * p.A;
+    long long off = 0;
+    int n = 0;
+    bool ok = idx >= 0 && idx < ex.n_examples;
+    if (ok) {
+        off = ex.sp_off64 ? ex.sp_off64[idx] : (long long)ex.sp_off32[idx];
+        n = ex.sp_n[idx];
+        ok = off >= 0 && n >= 0 && off + n <= ex.n_sparse;
+    }
+    if (!ok) {  // an index outside the arrays (or a corrupt entry): a zero row and a reported error, never a stray access
+        if (lane == 0) { set_error(p, ERR_BAD_EXAMPLE); value[k] = 0.f; }
+        for (int a = lane; a < p.A; a += 64) row[a] = 0.f;
+        float *pl = planes + (size_t)k * (p.N + 1) * p.H * p.W;
+        for (int a = lane; a < (p.N + 1) * p.H * p.W; a += 64) pl[a] = 0.f;
+        return;
+    }
     const u32 *key = ex.key + (size_t)idx * p.KW;
     row_t myrow = lane < p.H ? ((const row_t *)key)[lane] : (row_t)0;
     const u32 *rw = key + p.H * p.RW;
@@ -1646,9 +1682,6 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, PackedE
     if (p.RMW > 2) rem1 = rw[2];
     if (p.RMW > 3) rem1 |= (u64)rw[3] << 32;
     write_planes<row_t>(p, ex.wh + (size_t)idx * p.N * 2, myrow, rem0, rem1, planes + (size_t)k * (p.N + 1) * p.H * p.W);
-    const long long off = ex.sp_off64 ? ex.sp_off64[idx] : (long long)ex.sp_off32[idx];
-    const int n = ex.sp_n[idx];
-    float *row = pi + (size_t)k * p.A;
     for (int a = lane; a < p.A; a += 64) row[a] = 0.f;
     u64 total = 0;
     for (int q = lane; q < n; q += 64) total += ex.sp_cnt[off + q];
@@ -1656,7 +1689,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_examples(DP p, PackedE
     for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
     const double ds = (double)total;  // counts_sum = float(sum(counts))
     wave_sync();
-    for (int q = lane; q < n; q += 64) row[ex.sp_act[off + q]] = (float)((double)ex.sp_cnt[off + q] / ds);
+    for (int q = lane; q < n; q += 64) {
+        const int a = ex.sp_act[off + q];
+        if (a < p.A) row[a] = (float)((double)ex.sp_cnt[off + q] / ds); else set_error(p, ERR_BAD_EXAMPLE);
+    }
     if (lane == 0) value[k] = (float)ex.value[idx];
 }
 
@@ -2709,10 +2745,10 @@ static int check_device_error(rp_ctx *ctx) {
     (void)hipMemsetAsync(ctx->d.error, 0, sizeof(int), ctx->stream);
     static const char *names[] = {"", "node arena overflow (raise node_cap)", "legal-move arena overflow (raise edge_cap)",
                                   "transposition table full", "action is not a legal move of the (expanded) root", "search path broken",
-                                  "finished-episode ring overflow", "replay buffer full (raise max_examples)",
-                                  "visited-edge arena overflow (raise vis_cap)"};
-    int code = (e == ERR_BAD_ACTION) ? RP_ERR_ASSERT : (e == ERR_PATH ? RP_ERR_STATE : RP_ERR_CAPACITY);
-    return fail(ctx, code, "device error %d: %s", e, e < 9 ? names[e] : "?");
+                                  "finished-episode ring overflow", "replay buffer full (raise max_examples / max_sparse)",
+                                  "visited-edge arena overflow (raise vis_cap)", "replay example index or sparse entry outside the packed arrays"};
+    int code = (e == ERR_BAD_ACTION) ? RP_ERR_ASSERT : (e == ERR_PATH ? RP_ERR_STATE : (e == ERR_BAD_EXAMPLE ? RP_ERR_ARG : RP_ERR_CAPACITY));
+    return fail(ctx, code, "device error %d: %s", e, e < 10 ? names[e] : "?");
 }
 
 // leaves and combine schedule of NumPy's pairwise sum over n elements (oracle: pairwise_sum)
@@ -2879,8 +2915,8 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     if (STAGE_BYTES(d) + 9 * 1024 > 64 * 1024) {  // A > ~6 900: static (8 KB) + staging LDS pass the default 64 KB limit
         const size_t lim = STAGE_BYTES(d) + 9 * 1024;
         const void *fns[5];
-        if (ctx->row64) { fns[0] = (const void *)k_search<u64>; fns[1] = (const void *)k_moves<u64>; fns[2] = (const void *)k_set_roots<u64>; fns[3] = (const void *)k_advance<u64>; fns[4] = (const void *)k_pool_begin<u64>; }
-        else { fns[0] = (const void *)k_search<u32>; fns[1] = (const void *)k_moves<u32>; fns[2] = (const void *)k_set_roots<u32>; fns[3] = (const void *)k_advance<u32>; fns[4] = (const void *)k_pool_begin<u32>; }
+        if (ctx->row64) { fns[0] = d.N > 64 ? (const void *)k_search<u64, true> : (const void *)k_search<u64, false>; fns[1] = (const void *)k_moves<u64>; fns[2] = (const void *)k_set_roots<u64>; fns[3] = (const void *)k_advance<u64>; fns[4] = (const void *)k_pool_begin<u64>; }
+        else { fns[0] = d.N > 64 ? (const void *)k_search<u32, true> : (const void *)k_search<u32, false>; fns[1] = (const void *)k_moves<u32>; fns[2] = (const void *)k_set_roots<u32>; fns[3] = (const void *)k_advance<u32>; fns[4] = (const void *)k_pool_begin<u32>; }
         for (const void *fn : fns) {
             const int rc2 = allow_lds(ctx, fn, lim, "rp_create (legal-move staging of the tree kernels)");
             if (rc2 != RP_OK) {
@@ -3097,7 +3133,14 @@ extern "C" int rp_search_step(rp_ctx *ctx, int32_t *n_leaves_out) {
     if (!ctx) return RP_ERR_ARG;
     DP &d = ctx->d;
     if (d.move_rule != RP_MOVE_EXTERNAL) DISPATCH_STAGED(ctx, k_moves, grid_for(d.G), d);
-    DISPATCH_STAGED(ctx, k_search, grid_for(d.G), d);
+    {
+        const dim3 grid(grid_for(d.G)), block(64 * WAVES_PER_BLOCK);
+        const size_t lds = STAGE_BYTES(d);
+        if (ctx->row64) { if (d.N > 64) hipLaunchKernelGGL((k_search<u64, true>), grid, block, lds, ctx->stream, d); else hipLaunchKernelGGL((k_search<u64, false>), grid, block, lds, ctx->stream, d); }
+        else { if (d.N > 64) hipLaunchKernelGGL((k_search<u32, true>), grid, block, lds, ctx->stream, d); else hipLaunchKernelGGL((k_search<u32, false>), grid, block, lds, ctx->stream, d); }
+        hipError_t le_ = hipGetLastError();
+        if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of k_search failed: %s", hipGetErrorString(le_));
+    }
     // Without a count request nothing is synchronised and evaluator row b belongs to slot b (fixed shapes for graph capture);
     // with one, the waiting slots are listed in slot order and rows follow that list.
     d.rows_identity = (n_leaves_out || ctx->compact_rows) ? 0 : 1;
@@ -3570,7 +3613,7 @@ extern "C" int rp_examples_count(rp_ctx *ctx, int64_t *n_out) {
 static PackedEx own_examples(const DP &d) {
     PackedEx ex;
     ex.key = d.ex_key; ex.wh = d.ex_wh; ex.value = d.ex_value; ex.sp_off64 = nullptr; ex.sp_off32 = d.ex_sp_off; ex.sp_n = (const int *)d.ex_sp_n;
-    ex.sp_act = d.ex_sp_act; ex.sp_cnt = d.ex_sp_cnt;
+    ex.sp_act = d.ex_sp_act; ex.sp_cnt = d.ex_sp_cnt; ex.n_examples = d.max_examples; ex.n_sparse = d.sp_cap;
     return ex;
 }
 
@@ -3601,7 +3644,8 @@ extern "C" int rp_examples_packed_count(rp_ctx *ctx, int64_t *n_examples_out, in
 
 extern "C" int rp_examples_packed(rp_ctx *ctx, int64_t n_examples, int64_t n_sparse, uint32_t *key_dev, uint8_t *item_wh_dev, int32_t *value_dev,
                                   int32_t *sp_off_dev, int32_t *sp_n_dev, uint16_t *sp_act_dev, uint32_t *sp_cnt_dev, int64_t *episode_dev, int32_t *move_dev) {
-    if (!ctx || n_examples < 0 || n_sparse < 0 || !key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev || !sp_act_dev || !sp_cnt_dev)
+    if (!ctx || n_examples < 0 || n_sparse < 0 || (n_examples > 0 && (!key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev)) ||
+        (n_sparse > 0 && (!sp_act_dev || !sp_cnt_dev)))
         return fail(ctx, RP_ERR_ARG, "rp_examples_packed: bad argument");
     int64_t n = 0, ns = 0;
     int rc = rp_examples_packed_count(ctx, &n, &ns);
@@ -3625,17 +3669,24 @@ extern "C" int rp_examples_packed(rp_ctx *ctx, int64_t n_examples, int64_t n_spa
     return RP_OK;
 }
 
-extern "C" int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, const uint32_t *key_dev, const uint8_t *item_wh_dev, const int32_t *value_dev,
-                                  const int64_t *sp_off_dev, const int32_t *sp_n_dev, const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev,
-                                  float *pi_dev, float *value_out_dev) {
-    if (!ctx || n < 0 || !key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev || !sp_act_dev || !sp_cnt_dev || !planes_dev || !pi_dev || !value_out_dev)
+extern "C" int rp_expand_examples(rp_ctx *ctx, int64_t n, const int64_t *index_dev, int64_t n_examples, int64_t n_sparse, const uint32_t *key_dev,
+                                  const uint8_t *item_wh_dev, const int32_t *value_dev, const int64_t *sp_off_dev, const int32_t *sp_n_dev,
+                                  const uint16_t *sp_act_dev, const uint32_t *sp_cnt_dev, float *planes_dev, float *pi_dev, float *value_out_dev) {
+    if (!ctx || n < 0 || n_examples < 0 || n_sparse < 0 || !planes_dev || !pi_dev || !value_out_dev ||
+        (n_examples > 0 && (!key_dev || !item_wh_dev || !value_dev || !sp_off_dev || !sp_n_dev)) || (n_sparse > 0 && (!sp_act_dev || !sp_cnt_dev)))
         return fail(ctx, RP_ERR_ARG, "rp_expand_examples: bad argument");
     if (n == 0) return RP_OK;
+    if (!index_dev && n > n_examples) return fail(ctx, RP_ERR_ARG, "rp_expand_examples: %lld rows asked of %lld examples", (long long)n, (long long)n_examples);
     PackedEx ex;
     ex.key = key_dev; ex.wh = item_wh_dev; ex.value = value_dev; ex.sp_off64 = (const long long *)sp_off_dev; ex.sp_off32 = nullptr; ex.sp_n = sp_n_dev;
-    ex.sp_act = sp_act_dev; ex.sp_cnt = sp_cnt_dev;
+    ex.sp_act = sp_act_dev; ex.sp_cnt = sp_cnt_dev; ex.n_examples = n_examples; ex.n_sparse = n_sparse;
     DISPATCH(ctx, k_examples, grid_for(n), ctx->d, ex, 0LL, (long long)n, (const long long *)index_dev, planes_dev, pi_dev, value_out_dev);
     return RP_OK;
+}
+
+extern "C" int rp_check(rp_ctx *ctx) {
+    if (!ctx) return RP_ERR_ARG;
+    return check_device_error(ctx);
 }
 
 extern "C" int rp_examples_meta(rp_ctx *ctx, int64_t first, int64_t count, uint64_t *episode_id_out, int32_t *move_out) {

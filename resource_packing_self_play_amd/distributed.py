@@ -20,6 +20,14 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if os.environ.get("RP_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # one MIOpen user database / kernel cache per rank: the ranks of a node meet every new convolution shape (training batches,
+        # first waves) at the same moment, and concurrent writers of one sqlite file are a known source of rare start-up failures
+        base = os.environ.get("RP_MIOPEN_DIR", "/tmp/rp_miopen_%d" % os.getuid())
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(base, "rank%d" % rank, "db"))
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(base, "rank%d" % rank, "cache"))
+        for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
+            os.makedirs(os.environ[k], exist_ok=True)
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("RP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -134,6 +134,11 @@ class PackedReplay:
     def dense(self):
         return self.expand(None)
 
+    def check(self):
+        """Synchronises and raises if the expand kernel met an index or a pool entry outside this set's arrays."""
+        if self.device.type == "cuda":
+            expander(self.W, self.H, self.N, self.device).check()
+
     # ---- one flat byte buffer (the all-gather payload, the on-disk form) ------------------------------------------------------
     def to_flat(self):
         """uint8 1-D tensor: int64 header [E, S, KW, has_meta], then every array padded to 8 bytes."""

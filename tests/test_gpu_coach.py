@@ -217,11 +217,11 @@ def test_two_ranks_play_and_train_like_one(tmp_path):
         for r in range(world):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                        RP_DIST_BACKEND="gloo", RP_SINGLE_DEVICE="1")
-            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_coach_worker.py"), str(tmp_path), str(world)], env=env,
+            procs.append(subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(HERE, "dist_coach_worker.py"), str(tmp_path), str(world)], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        for r, p in enumerate(procs):
-            out, _ = p.communicate(timeout=600)
-            assert p.returncode == 0, "world %d rank %d failed:\n%s" % (world, r, out[-3000:])
+        logs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "world %d failed:\n%s" % (world, "\n".join("---- rank %d (rc %s)\n%s" % (r, p.returncode, o[-2500:]) for r, (p, o) in enumerate(zip(procs, logs))))
+        for r in range(world):
             outs[(world, r)] = np.load(os.path.join(str(tmp_path), "coach_w%d_r%d.npz" % (world, r)))
     a, b, solo = outs[(2, 0)], outs[(2, 1)], outs[(1, 0)]
     for key in ("scores", "planes", "pi", "value", "scores2"):
@@ -297,7 +297,7 @@ def test_packed_replay_expands_like_the_dense_tensors_and_trains_the_same(tmp_pa
             assert np.array_equal(planes[k].cpu().numpy(), planes_from_state(rows_k, rem, whs[k], W, H))
             want = np.zeros(A)
             want[acts[off[k]:off[k] + cnt_n[k]]] = cnts[off[k]:off[k] + cnt_n[k]]
-            assert want.sum() == sims or int(rep.move[k]) > 0  # the first move's root has exactly numMCTSSims visits
+            assert want.sum() == sims - 1 or int(rep.move[k]) > 0  # a fresh root: the first simulation expands it, the other numMCTSSims - 1 pass an edge
             assert np.array_equal(pi[k].cpu().numpy(), (want / float(want.sum())).astype(np.float32))
             assert float(value[k]) == fin[int(rep.episode[k])]
         # (c) an index list with repeats, out of order
@@ -313,8 +313,12 @@ def test_packed_replay_expands_like_the_dense_tensors_and_trains_the_same(tmp_pa
             w1 = {k: v.clone() for k, v in nnet.nnet.state_dict().items()}
             nnet.nnet.load_state_dict(w0)
             np.random.seed(77); h2 = nnet.train_tensors(planes, pi, value)
-            assert nnet.last_train_steps == 2 * (E // 16) and h1 == h2
-            assert all(torch.equal(w1[k], v) for k, v in nnet.nnet.state_dict().items())
+            # the batches are bit-identical (c); MIOpen's weight-gradient kernels accumulate with atomics, so two runs of the SAME
+            # training agree to float32 summation order, not bit for bit
+            assert nnet.last_train_steps == 2 * (E // 16) and np.allclose(np.array(h1), np.array(h2), rtol=1e-5, atol=1e-7)
+            worst = max(float((w1[k].float() - v.float()).abs().max()) for k, v in nnet.nnet.state_dict().items())
+            print("train_packed vs train_tensors after %d steps: losses %s vs %s, max weight delta %.2e" % (nnet.last_train_steps, h1[-1], h2[-1], worst))
+            assert worst < 2e-3  # Adam turns rounding-level gradient noise into steps of up to lr = 1e-3 on entries with ~zero gradient
         sp.close()
 
 
