@@ -621,10 +621,10 @@ def main(argv=None):
                         ev[0].record(); g0.eng.search_step(sync=False)
                         if sp.compact_rows:
                             g0.eng.leaf_count_async(cnt_host, cnt_used[0] % cnt_host.numel()); cnt_used[0] += 1
-                        ev[1].record(); g0.eng.leaf_stem(g0.stem.data_ptr(), g0.G, g0.stem_relu.data_ptr() if g0.stem_relu is not None else None, g0.channels_last) if g0.use_stem else g0.eng.leaf_planes(g0.planes.data_ptr(), g0.G)
+                        ev[1].record(); g0.leaf_inputs()
                         g0.eng.kernel_events = kev
                         ev[2].record(); pi, v = g0.forward(sp.nnet)
-                        ev[3].record(); g0.eng.kernel_events = None; g0.eng.commit_eval(pi.data_ptr(), v.data_ptr())
+                        ev[3].record(); g0.eng.kernel_events = None; g0.commit(pi, v)
                         ev[4].record()
                     for g in sp.groups[1:]:
                         sp.step_group(g)

@@ -233,6 +233,10 @@ int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out /*[n][H]*/,
  * pi_dev [n][W*N] and v_dev [n] are DEVICE float32 (probabilities, i.e. exp(log_softmax), NNet.py:85),
  * row b belonging to the b-th waiting leaf. */
 int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev);
+/* The same from the policy head's raw outputs (logits_fc, BinpackingNNet.py:69,79): the softmax of NNet.predict (NNet.py:81-85:
+ * exp(log_softmax(x))) is taken inside the kernel, float32, exp(x - max) / sum -- no separate softmax pass over [n][W*N].
+ * W * N <= 1536 (the row lives in LDS); larger action spaces take the softmax first and call rp_commit_eval. */
+int rp_commit_eval_logits(rp_ctx *ctx, const float *logits_dev, const float *v_dev);
 /* Same with HOST float32 buffers (tests, CPU evaluators). */
 int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows);
 

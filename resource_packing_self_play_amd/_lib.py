@@ -77,6 +77,7 @@ _SIGS = {
     "rp_nn_bias_pool": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32]),
     "rp_leaf_states": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "rp_commit_eval": (C.c_int, [_vp, _vp, _vp]),
+    "rp_commit_eval_logits": (C.c_int, [_vp, _vp, _vp]),
     "rp_commit_eval_host": (C.c_int, [_vp, _vp, _vp, _i32]),
     "rp_root_counts": (C.c_int, [_vp, _i32, _i32, _vp]),
     "rp_game_status": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
@@ -333,10 +334,10 @@ class Engine:
                                          C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W))
 
     def nn_resstage16(self, x, frag4, bias4, out, out_relu=None):
-        """Both residual blocks of a 16-channel stage on channels-last x [B, 16, H, W] (H * W <= 128) in one launch."""
+        """Both residual blocks of a 16-channel stage on channels-last x [B, 16, H, W] (H * W <= 640) in one launch."""
         B, Cc, H, W = x.shape
-        if Cc != 16 or self._bchw(x)[2] != 1 or H * W > 128:
-            raise ValueError("nn_resstage16 needs a channels-last [B, 16, H, W] tensor with H * W <= 128")
+        if Cc != 16 or self._bchw(x)[2] != 1 or H * W > 640:
+            raise ValueError("nn_resstage16 needs a channels-last [B, 16, H, W] tensor with H * W <= 640")
         self._timed("k_resstage16 %dx%d" % (H, W), lambda: self._ck(self.L.rp_nn_resstage16(
             self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()), C.c_void_p(out.data_ptr()),
             C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W)))
@@ -355,10 +356,10 @@ class Engine:
             self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag.data_ptr()), C.c_void_p(bias.data_ptr()), C.c_void_p(out.data_ptr()), B, Cc, H, W)))
 
     def nn_resstage32(self, x, frag4, bias4, out, out_relu=None):
-        """Both residual blocks of a 32-channel stage on channels-last x [B, 32, H, W] (H * W <= 80) in one launch."""
+        """Both residual blocks of a 32-channel stage on channels-last x [B, 32, H, W] (H * W <= 512) in one launch."""
         B, Cc, H, W = x.shape
-        if Cc != 32 or self._bchw(x)[2] != 1 or H * W > 80:
-            raise ValueError("nn_resstage32 needs a channels-last [B, 32, H, W] tensor with H * W <= 80")
+        if Cc != 32 or self._bchw(x)[2] != 1 or H * W > 512:
+            raise ValueError("nn_resstage32 needs a channels-last [B, 32, H, W] tensor with H * W <= 512")
         self._timed("k_resstage32 %dx%d" % (H, W), lambda: self._ck(self.L.rp_nn_resstage32(
             self.h, C.c_void_p(x.data_ptr()), C.c_void_p(frag4.data_ptr()), C.c_void_p(bias4.data_ptr()), C.c_void_p(out.data_ptr()),
             C.c_void_p(out_relu.data_ptr()) if out_relu is not None else None, B, H, W)))
@@ -424,6 +425,11 @@ class Engine:
 
     def commit_eval(self, pi_dev_ptr, v_dev_ptr):
         self._ck(self.L.rp_commit_eval(self.h, C.c_void_p(pi_dev_ptr), C.c_void_p(v_dev_ptr)))
+
+    LOGITS_MAX_ACTIONS = 1536  # rp_commit_eval_logits keeps a row in LDS
+
+    def commit_eval_logits(self, logits_dev_ptr, v_dev_ptr):
+        self._ck(self.L.rp_commit_eval_logits(self.h, C.c_void_p(logits_dev_ptr), C.c_void_p(v_dev_ptr)))
 
     def commit_eval_host(self, pi, v):
         pi = _arr(pi, np.float32); n = pi.shape[0]

@@ -89,6 +89,10 @@ class BinPackingNNet(nn.Module):
     # entry is exactly one weight) and refreshed in place after weight updates, which keeps captured HIP graphs valid.
     # Both memory orders are kept: NCHW-flattened (c, h, w) and channels-last-flattened (h, w, c).
     DENSE_MAX_PIXELS = 9
+    # image sizes the engine's stage kernels take: one wave per group of leaves up to 128 / 80 pixels, one workgroup per group of leaves
+    # above that (rp_nn_resstage16 / rp_nn_resstage32 / rp_nn_convpool32: 25x25x16 and 13x13x32 at the 50x50 board)
+    STAGE16_MAX_PIXELS = 640
+    STAGE32_MAX_PIXELS = 512
     use_resblock_kernel = True
     fused_linear_relu = hasattr(torch, "_addmm_activation")
 
@@ -121,7 +125,7 @@ class BinPackingNNet(nn.Module):
 
     def refresh_frags(self, ops):
         """MFMA B-fragment copies of the residual convolutions for the engine's fused stage kernels (rp_nn_resstage16 for
-        16-channel stages on <= 128-pixel images, rp_nn_resstage32 for 32-channel stages on <= 80-pixel images; rp_nn_resblock16
+        16-channel stages on <= 640-pixel images, rp_nn_resstage32 for 32-channel stages on <= 512-pixel images; rp_nn_resblock16
         takes single 16-channel blocks); refreshed in place after weight updates.  The four fragments of a stage are slices
         of one buffer, next to a [4][C] copy of the biases, both in execution order."""
         if not hasattr(self, "_dense"):
@@ -131,7 +135,7 @@ class BinPackingNNet(nn.Module):
         with torch.no_grad():
             for si, stage in enumerate(self.conv_seqs):
                 ch, h, w = shapes[si]
-                if not ((ch == 16 and h * w <= 128) or (ch == 32 and h * w <= 80)):
+                if not ((ch == 16 and h * w <= self.STAGE16_MAX_PIXELS) or (ch == 32 and h * w <= self.STAGE32_MAX_PIXELS)):
                     continue
                 n = 36 * 64 * (ch // 16) ** 2
                 skey, bkey = "stagefrag:%d" % si, "stagebias:%d" % si
@@ -153,7 +157,7 @@ class BinPackingNNet(nn.Module):
                 if si == 0 or shapes[si][0] != 32:
                     continue
                 cin, h, w = shapes[si - 1]
-                if not ((cin == 16 and h * w <= 112) or (cin == 32 and h * w <= 80)):
+                if not ((cin == 16 and h * w <= self.STAGE16_MAX_PIXELS) or (cin == 32 and h * w <= self.STAGE32_MAX_PIXELS)):
                     continue
                 key = "entryfrag:%d" % si
                 if key not in self._dense:
@@ -177,13 +181,14 @@ class BinPackingNNet(nn.Module):
             return torch.mm(x.permute(0, 2, 3, 1).reshape(b, -1), mt).view(b, h, w, conv.out_channels).permute(0, 3, 1, 2)
         return torch.mm(x.flatten(1), mt).view(b, conv.out_channels, h, w)
 
-    def forward_from_stem_fused(self, y, y_relu, ops):
+    def forward_from_stem_fused(self, y, y_relu, ops, logits=False):
         """Same network as forward_from_stem with the element-wise work fused: convolutions run without bias through
         PyTorch-ROCm, and `ops` (an engine: rp_nn_bias_relu / rp_nn_bias_residual / rp_nn_bias_pool) applies bias + ReLU,
         bias + skip (+ the next block's ReLU) and bias + max-pool in one pass each -- 4 kernels per residual block
         instead of 7, the same float32 operations in the same order.  Convolutions on <= 3x3 images run as one GEMM each
         when refresh_dense() has been called.  Works on NCHW-contiguous or channels-last tensors (MIOpen's FP32 kernels
-        are 20-30 % faster on the latter).  y_relu = relu(y).  Returns (softmax, tanh)."""
+        are 20-30 % faster on the latter).  y_relu = relu(y) or None.  Returns (softmax, tanh) -- or (raw logits, tanh) with
+        `logits=True`, for rp_commit_eval_logits, which takes the softmax inside the commit kernel."""
         cl = self._is_cl(y)
         fmt = torch.channels_last if cl else torch.contiguous_format
         x, xr = y, y_relu
@@ -235,7 +240,8 @@ class BinPackingNNet(nn.Module):
             ops.nn_value_head(z, self.value_fc.weight, self.value_fc.bias, v)
         else:
             v = torch.tanh(self.value_fc(z))
-        return torch.softmax(self.logits_fc(z), dim=1), v
+        out = self.logits_fc(z)
+        return (out if logits else torch.softmax(out, dim=1)), v
 
     def forward_from_stem(self, y):
         """y = max_pool2d(conv_seqs[0].conv(x), 3, 2, 1), e.g. from the engine's rp_leaf_stem: the rest of the network."""

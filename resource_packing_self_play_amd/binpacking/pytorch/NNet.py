@@ -57,15 +57,17 @@ class NNetWrapper(NeuralNet):
         if self.device.type == "cuda":
             self.nnet.refresh_dense()
 
-    def predict_from_stem(self, stem, stem_relu=None, ops=None):
+    def predict_from_stem(self, stem, stem_relu=None, ops=None, logits=False):
         """stem: float32 [B, 16, (H+1)//2, (W+1)//2] from rp_leaf_stem -> (pi [B, A], v [B]) like predict_batch.
         With `ops` (the engine) the element-wise work runs through the engine's fused kernels; `stem_relu` (= relu(stem), which
         rp_leaf_stem can write alongside) is only read when stage 0 runs on the library path -- the stage kernel takes `stem` alone."""
         self.nnet.eval()
         with torch.no_grad():
             if ops is not None:
-                pi, v = self.nnet.forward_from_stem_fused(stem, stem_relu, ops)
+                pi, v = self.nnet.forward_from_stem_fused(stem, stem_relu, ops, logits=logits)  # logits: raw policy outputs for rp_commit_eval_logits
                 return pi.contiguous(), v.reshape(-1).contiguous()
+            if logits:
+                raise ValueError("raw logits are only returned by the fused path (ops = the engine)")
             log_pi, v = self.nnet.forward_from_stem(stem)
             return torch.exp(log_pi).contiguous(), v.reshape(-1).contiguous()
 

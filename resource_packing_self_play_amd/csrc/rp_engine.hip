@@ -1202,11 +1202,17 @@ __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, flo
 }
 
 // Expansion + backup for the waiting leaves (MCTS_bpp.py:87-104 then :130-139 up the path).
-template <typename row_t>
+// LOGITS: `pi` holds the policy head's raw outputs (logits_fc, BinpackingNNet.py:69,79) and the softmax of NNet.predict
+// (exp(log_softmax(x)), NNet.py:81-85) is taken here -- the row goes to LDS once, max / exp / sum / divide run in the wave, and the
+// masked NumPy-order sum below reads the probabilities from LDS: the separate softmax pass over the [rows][A] matrix (one read + one
+// write of 84 MB per wave of 32 768 leaves at 20x20 / 32) and the re-read by this kernel are gone.  float32 like torch.softmax:
+// exp(x - max) / sum, the sum taken lane-wise then across lanes (the policy tolerance is 1e-5, not bit equality with one library).
+template <typename row_t, bool LOGITS>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const float *pi, const float *vv) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
     __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
+    extern __shared__ float s_soft[];  // LOGITS: [WAVES_PER_BLOCK][A]
     const int b = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id(), wv = wave_in_block();
     if (b >= (p.rows_identity ? p.G : *p.eval_count)) return;
     const int g = __builtin_amdgcn_readfirstlane(p.rows_identity ? b : p.eval_slot[b]);
@@ -1219,14 +1225,34 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     u32 e0 = 0, n0 = 0, e1 = 0, n1 = 0;  // path entries of levels lane and 64 + lane (entries past `depth` are stale and unused)
     if (lane < p.N) { e0 = pe[lane]; n0 = pn[lane]; }
     if (lane + 64 < p.N) { e1 = pe[lane + 64]; n1 = pn[lane + 64]; }
+    const float *row = pi + (size_t)b * p.A;
+    if (LOGITS) {  // the row's logits are requested with the slot's state
+        float *sp = s_soft + (size_t)wv * p.A;
+        for (int a = lane; a < p.A; a += 64) sp[a] = row[a];
+    }
     if (uni(phase) != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     NodeHdr hd = t.load_hdr(uni(node));
     // backup along the stored path (:130-139) first: its loads travel with the header's
     if (lane < depth) t.backup_entry(n0, e0, v, RP_KIND_F32);
     if (lane + 64 < depth) t.backup_entry(n1, e1, v, RP_KIND_F32);
+    if (LOGITS) {
+        float *sp = s_soft + (size_t)wv * p.A;
+        wave_sync();
+        float m = -INFINITY;
+        for (int a = lane; a < p.A; a += 64) m = fmaxf(m, sp[a]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int a = lane; a < p.A; a += 64) { const float e = expf(sp[a] - m); sp[a] = e; sum += e; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int a = lane; a < p.A; a += 64) sp[a] = sp[a] / sum;
+        wave_sync();
+        row = sp;
+    }
     bool fb;
-    double norm = masked_prior(p, pi + (size_t)b * p.A, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
+    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
         hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
         t.hdr[node] = hd;
@@ -1431,13 +1457,14 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
         float *ob = out + (size_t)b * STEM_C * P;
         // A lane owns the 2x2 block of convolution outputs (2pr + {0,1}, 2px + {0,1}) of pooled pixel (pr, px): every output is
         // computed exactly once; the 3x3/2 window's other five outputs come from the left / upper / upper-left lanes by
-        // shuffle.  A pass covers rpp pooled rows; passes after the first start one row early (halo row: computed, not stored).
-        const int rpp = 64 / p.Wp;
-        const int lr = lane / p.Wp, px = lane - lr * p.Wp;
-        for (int base = 0, pass = 0; base + (pass ? 1 : 0) < p.Hp; base += rpp - 1, ++pass) {
+        // shuffle.  A pass covers 64 CONSECUTIVE pooled pixels in row-major order (lane = pixel: every lane works whatever the image
+        // width -- whole rows per pass left 14 of 64 lanes idle at the 50x50 board and spent half of the rest on the halo row); passes
+        // after the first start one image row + one pixel early (their first Wp + 1 lanes are the halo -- the upper and upper-left
+        // neighbours of the first stored pixel: computed, not stored).
+        for (int base = 0, pass = 0; base + (pass ? p.Wp + 1 : 0) < P; base += 63 - p.Wp, ++pass) {
             if (!T_LDS && (pass & (WAVES_PER_BLOCK - 1)) != wv_) continue;
-            const int pr = base + lr;
-            const bool live = lr < rpp && pr < p.Hp;
+            const int pq = base + lane, pr = pq / p.Wp, px = pq - pr * p.Wp;
+            const bool live = pq < P;
             const int ra = 2 * pr, xa = 2 * px;
             const bool rbok = live && ra + 1 < p.H, xbok = xa + 1 < p.W;
             row_t rw[4];  // grid rows 2pr-1 .. 2pr+2 (zero outside the grid); shuffles need every lane
@@ -1492,7 +1519,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
             }
             // max-pool on the integers: own block, then the right column of the left lane, the bottom row of the upper lane, the corner
             // of the upper-left; one conversion to float32 per pooled value
-            const bool has_l = px > 0, has_u = lr > 0;
+            const bool has_l = px > 0, has_u = lane >= p.Wp;  // the lane one image row up is in this pass (row 0 has nothing above it)
             float best[STEM_C];
 #pragma unroll
             for (int o = 0; o < STEM_C; ++o) {
@@ -1504,8 +1531,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                 const int nb = max(max(has_l ? fl : STEM_NEG_INF, has_u ? fu : STEM_NEG_INF), (has_l && has_u) ? fc : STEM_NEG_INF);
                 best[o] = (float)max(own, nb) * unit[o];
             }
-            const bool store = live && (pass == 0 || lr > 0);
-            const int pp = pr * p.Wp + px;
+            const bool store = live && (pass == 0 || lane > p.Wp);
+            const int pp = pq;
             if (store && nhwc) {  // channels-last: a pixel's 16 channels are contiguous -> four 16-byte stores per lane
                 float4 *o4 = (float4 *)(ob + (size_t)pp * STEM_C);
 #pragma unroll
@@ -2652,6 +2679,262 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// The stage kernels for images that do not fit one wave (BASELINE configs[4]: 50x50 board -> 25x25x16, 13x13x32): one WORKGROUP per
+// task, the padded image(s) shared in LDS, the pixel tiles dealt to the workgroup's WAVES (4 or 8) waves in contiguous runs of NT
+// (accumulators and skip operands stay in registers as above, NT per wave instead of per image; eight waves keep NT <= 5 for 40 tiles
+// and put two waves on every SIMD, so one wave's barrier wait is another's MFMA time).  A convolution reads the whole image and its output
+// overwrites it IN PLACE: every wave finishes its MFMA stream (barrier), then all waves write their tiles (barrier).  The MFMA
+// streams, fragment orders and epilogue arithmetic are the wave kernels' (rs_conv / r32_conv): same float32 operations in the same
+// order per pixel, so the results are bit-identical to them on images both can take.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_resstage16_wg(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
+                                                          float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w,
+                                                          const int *__restrict__ nrows_dev) {
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = wave_in_block();
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
+    if ((long long)blockIdx.x >= B) return;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RS_STRIDE;
+    float *img = rb_lds;  // [IMG] + one dummy pixel
+    {
+        float4 *z4 = (float4 *)img;
+        for (int i = threadIdx.x; i < (IMG + RS_STRIDE) / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // borders stay zero
+    }
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pdst[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = (wv * NT + t) * 16 + n, mm = m < PIX ? m : 0, r = mm / S_w, c = mm - r * S_w, pc = ((r + 1) * PW + c + 1) * RS_STRIDE;
+        abase[t] = pc - (PW + 1) * RS_STRIDE + 4 * g;
+        pdst[t] = (m < PIX ? pc : IMG) + 4 * g;  // rows past the image: the dummy pixel
+    }
+    f32x4 bias4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bias4[k] = *(const f32x4 *)(bias + 16 * k + 4 * g);
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 36 * 64 * 4, RS_BUF_FLAGS);
+    const int rowoff = n * 64 + g * 16, tile0 = wv * NT;
+    f32x4 xs[NT], wq[3];
+    wq[0] = rs_load_b(frs, lane * 16, 0); wq[1] = rs_load_b(frs, lane * 16, 1024);
+    __syncthreads();
+    for (long long leaf = blockIdx.x; leaf < B; leaf += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { xs[t] = rs_load_b(xrs, rowoff, (tile0 + t) * 1024); *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // zeros past the image
+        f32x4 acc[NT];
+        __syncthreads();
+        rs_conv<NT>(img, frs, 0, 9 * 1024, PW, abase, acc, wq);              // block 0, conv0
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[0]);
+        __syncthreads();
+        rs_conv<NT>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq);      // block 0, conv1 (+ skip x)
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { xs[t] = (acc[t] + bias4[1]) + xs[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }
+        __syncthreads();
+        rs_conv<NT>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq);     // block 1, conv0
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[2]);
+        __syncthreads();
+        rs_conv<NT>(img, frs, 27 * 1024, 0, PW, abase, acc, wq);             // block 1, conv1 (+ skip y1)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = (acc[t] + bias4[3]) + xs[t];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, (tile0 + t) * 1024, 0);  // dropped past the image
+        }
+        if (out_relu != nullptr) {
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, (tile0 + t) * 1024, 0);
+        }
+        __syncthreads();  // every wave has read the image: the next task may overwrite it
+    }
+}
+
+// 32-channel stage, IMGW leaves per workgroup (13x13: three leaves = 507 of 512 tile rows).  Swizzled image without padding floats.
+template <int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
+                                                          float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
+                                                          const int *__restrict__ nrows_dev) {
+    constexpr int CIN = 32;
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = wave_in_block();
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
+    if ((long long)blockIdx.x * IMGW >= B) return;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX, WG_P = IMGW * IMGP + 1;  // pixels incl. the dummy
+    float *sbias = rb_lds;  // [4][32]
+    float *img = sbias + 128;
+    for (int i = threadIdx.x; i < 128; i += 64 * WAVES) sbias[i] = bias[i];
+    {
+        float4 *z4 = (float4 *)img;
+        for (int i = threadIdx.x; i < WG_P * CIN / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pdst[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = (wv * NT + t) * 16 + n, mm = m < MP ? m : 0, im = mm / PIX, pq = mm - im * PIX, r = pq / S_w, c = pq - r * S_w;
+        const int pix = im * IMGP + (r + 1) * PW + c + 1, pc = m < MP ? pix : IMGW * IMGP;
+        abase[t] = pix - (PW + 1);
+        pdst[t][0] = pc * CIN + 4 * ((g) ^ r32_swz<CIN>(pc));
+        pdst[t][1] = pc * CIN + 4 * ((4 + g) ^ r32_swz<CIN>(pc));
+    }
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 9 * CIN * 32 * 4, RS_BUF_FLAGS);
+    constexpr int CONV_BYTES = 9 * CIN * 32 * 4;
+    const int rowoff = n * 128 + g * 16, tile0 = wv * NT;
+    f32x4 xs[NT][2], wq[3][2];
+    wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
+    wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+    __syncthreads();
+    const long long stride_leaves = (long long)gridDim.x * IMGW;
+    for (long long leaf0 = (long long)blockIdx.x * IMGW; leaf0 < B; leaf0 += stride_leaves) {
+        const int nbytes = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX * 128;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                xs[t][mt] = rs_load_b(xrs, rowoff, (tile0 + t) * 2048 + 64 * mt);
+                *(f32x4 *)(img + pdst[t][mt]) = rs_relu(xs[t][mt]);
+            }
+        f32x4 acc[NT][2];
+#define R32_BIAS(k) const f32x4 ba = *(const f32x4 *)(sbias + 32 * (k) + 4 * g), bb = *(const f32x4 *)(sbias + 32 * (k) + 16 + 4 * g)
+        __syncthreads();
+        r32_conv<NT, CIN>(img, frs, 0, CONV_BYTES, PW, abase, acc, wq);
+        __syncthreads();
+        {
+            R32_BIAS(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
+        }
+        __syncthreads();
+        r32_conv<NT, CIN>(img, frs, CONV_BYTES, 2 * CONV_BYTES, PW, abase, acc, wq);
+        __syncthreads();
+        {
+            R32_BIAS(1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xs[t][0] = (acc[t][0] + ba) + xs[t][0]; xs[t][1] = (acc[t][1] + bb) + xs[t][1];
+                *(f32x4 *)(img + pdst[t][0]) = rs_relu(xs[t][0]); *(f32x4 *)(img + pdst[t][1]) = rs_relu(xs[t][1]);
+            }
+        }
+        __syncthreads();
+        r32_conv<NT, CIN>(img, frs, 2 * CONV_BYTES, 3 * CONV_BYTES, PW, abase, acc, wq);
+        __syncthreads();
+        {
+            R32_BIAS(2);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
+        }
+        __syncthreads();
+        r32_conv<NT, CIN>(img, frs, 3 * CONV_BYTES, 0, PW, abase, acc, wq);
+        {
+            R32_BIAS(3);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = (acc[t][0] + ba) + xs[t][0]; acc[t][1] = (acc[t][1] + bb) + xs[t][1];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, (tile0 + t) * 2048, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, (tile0 + t) * 2048 + 64, 0);
+            }
+        }
+#undef R32_BIAS
+        if (out_relu != nullptr) {
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, (tile0 + t) * 2048, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, (tile0 + t) * 2048 + 64, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Stage entry (3x3 convolution CIN -> 32 + bias + max_pool2d(3, 2, 1)) with one workgroup per IMGW leaves: convolution as above, the
+// output + bias goes to an LDS staging copy of rows of 36 floats (it overwrites the consumed input image), the whole workgroup pools.
+template <int NT, int CIN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
+                                                          float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wg_floats,
+                                                          const int *__restrict__ nrows_dev) {
+    constexpr int XQ = CIN / 16;
+    extern __shared__ __attribute__((aligned(16))) float rb_lds[];
+    const int lane = lane_id(), wv = wave_in_block();
+    if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
+    if ((long long)blockIdx.x * IMGW >= B) return;
+    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX;
+    const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
+    float *img = rb_lds;  // wg_floats: the padded input images + dummy pixel, later the staging rows
+    {
+        float4 *z4 = (float4 *)img;
+        for (int i = threadIdx.x; i < wg_floats / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int n = lane & 15, g = lane >> 4;
+    int abase[NT], pin[NT][XQ], m_row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = (wv * NT + t) * 16 + n, mm = m < MP ? m : 0, im = mm / PIX, pq = mm - im * PIX, r = pq / S_w, c = pq - r * S_w;
+        const int pix = im * IMGP + (r + 1) * PW + c + 1, pc = m < MP ? pix : IMGW * IMGP;
+        abase[t] = pix - (PW + 1);
+        m_row[t] = m;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * CIN + 4 * ((4 * q + g) ^ r32_swz<CIN>(pc));
+    }
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 9 * CIN * 32 * 4, RS_BUF_FLAGS);
+    const f32x4 ba = *(const f32x4 *)(bias + 4 * g), bb = *(const f32x4 *)(bias + 16 + 4 * g);
+    const int rowoff = n * (CIN * 4) + g * 16, tile0 = wv * NT;
+    f32x4 wq[3][2];
+    wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
+    wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+    const int cq = threadIdx.x & 7;
+    __syncthreads();
+    const long long stride_leaves = (long long)gridDim.x * IMGW;
+    for (long long leaf0 = (long long)blockIdx.x * IMGW; leaf0 < B; leaf0 += stride_leaves) {
+        const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)leaf0 * PIX * CIN), 0, nimg * PIX * CIN * 4, RS_BUF_FLAGS);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = rs_load_b(xrs, rowoff, (tile0 + t) * 16 * CIN * 4 + 64 * q);
+        f32x4 acc[NT][2];
+        __syncthreads();
+        r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (m_row[t] < 16 * ((MP + 15) / 16)) {  // rows past the last (partly filled) tile would land beyond the staging area
+                *(f32x4 *)(img + m_row[t] * 36 + 4 * g) = acc[t][0] + ba;
+                *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
+            }
+        __syncthreads();
+        float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
+        for (int pq = threadIdx.x >> 3; pq < nimg * PP; pq += 8 * WAVES) {
+            const int im = pq / PP, pp = pq - im * PP, pr = pp / Wp, px = pp - pr * Wp;
+            const int ctr = im * PIX + 2 * pr * S_w + 2 * px;
+            const int ou = pr > 0 ? -S_w : 0, od = 2 * pr + 1 < S_h ? S_w : 0, ol = px > 0 ? -1 : 0, orr = 2 * px + 1 < S_w ? 1 : 0;
+            const float4 *row = (const float4 *)(img + ctr * 36) + cq;
+            const float4 v0 = row[0], v1 = row[ol * 9], v2 = row[orr * 9], v3 = row[ou * 9], v4 = row[(ou + ol) * 9], v5 = row[(ou + orr) * 9],
+                         v6 = row[od * 9], v7 = row[(od + ol) * 9], v8 = row[(od + orr) * 9];
+            float4 m;
+            m.x = fmaxf(fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x)), fmaxf(fmaxf(v4.x, v5.x), fmaxf(fmaxf(v6.x, v7.x), v8.x)));
+            m.y = fmaxf(fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y)), fmaxf(fmaxf(v4.y, v5.y), fmaxf(fmaxf(v6.y, v7.y), v8.y)));
+            m.z = fmaxf(fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3.z)), fmaxf(fmaxf(v4.z, v5.z), fmaxf(fmaxf(v6.z, v7.z), v8.z)));
+            m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)), fmaxf(fmaxf(v4.w, v5.w), fmaxf(fmaxf(v6.w, v7.w), v8.w)));
+            o4[pq * 8 + cq] = m;
+        }
+        __syncthreads();
+        if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
+            float4 *z4 = (float4 *)img;
+            for (int i = threadIdx.x; i < wg_floats / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct rp_ctx {
@@ -2723,6 +3006,16 @@ static int pick_leaves_per_wave(long long B, int PIX, int imgw_max) {
         if (best < 0 || cost < best) { best = cost; pick = k; }
     }
     return pick;
+}
+
+// Leaves per WORKGROUP for the _wg stage kernels.  A CU works through its workgroups' pixel tiles at a fixed rate, so a launch takes
+// (workgroups on the busiest CU) x (tile slots of a workgroup = waves x tiles per wave): few large groups fill their tiles best but
+// quantise badly over the CUs (1 024 leaves in groups of 3 = 342 workgroups = 2 rounds on 86 CUs, 1 on the rest).  Cost for all B rows
+// plus, weighted 3 : 1, the ~92 % of them that hold a leaf in an average wave -- as pick_leaves_per_wave does for the wave kernels.
+static long long wg_group_cost(long long B, int k, int tile_slots, int n_cu) {
+    const long long typical = std::max<long long>(1, (long long)(0.92 * (double)B));
+    auto rounds = [&](long long rows) { const long long tasks = (rows + k - 1) / k; return (tasks + n_cu - 1) / n_cu; };
+    return (rounds(B) + 3 * rounds(typical)) * tile_slots;
 }
 
 static int grid_for(long long waves) { return (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK); }
@@ -3283,10 +3576,29 @@ extern "C" int rp_nn_resblock16(rp_ctx *ctx, const float *x_dev, const float *fr
 
 extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                                 int32_t H, int32_t W) {
-    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 128)
-        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: bad argument (images of at most 128 pixels)");
+    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 640)
+        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: bad argument (images of at most 640 pixels)");
     if (B == 0) return RP_OK;
     const int PIX = H * W;
+    if (PIX > 128) {  // one workgroup per image, the pixel tiles dealt to its four waves (k_resstage16_wg)
+        const int tiles = (PIX + 15) / 16, waves = tiles > 20 ? 8 : 4, nt = (tiles + waves - 1) / waves;
+        const size_t lds = ((size_t)(H + 2) * (W + 2) * RS_STRIDE + RS_STRIDE) * sizeof(float);
+        if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: a %dx%d image needs %zu bytes of LDS, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+        const dim3 grid((unsigned)std::min<long long>(B, (long long)ctx->n_cu * per_cu)), block(64 * waves);
+#define RSW_LAUNCH(NT_, WV_)                                                                                                                        \
+    case NT_ * 16 + WV_: {                                                                                                                          \
+        const int rc_ = allow_lds(ctx, (const void *)k_resstage16_wg<NT_, WV_>, lds, "rp_nn_resstage16"); if (rc_ != RP_OK) return rc_;            \
+        hipLaunchKernelGGL((k_resstage16_wg<NT_, WV_>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, ctx->nn_rows_dev); \
+    } break;
+        switch (nt * 16 + waves) {
+            RSW_LAUNCH(3, 4) RSW_LAUNCH(4, 4) RSW_LAUNCH(5, 4) RSW_LAUNCH(3, 8) RSW_LAUNCH(4, 8) RSW_LAUNCH(5, 8)
+            default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: unsupported image size");
+        }
+#undef RSW_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return RP_OK;
+    }
     const size_t img_bytes = (size_t)(H + 2) * (W + 2) * RS_STRIDE * sizeof(float);
     // leaves per wave: as many as fit 8 pixel tiles (accumulators + the kept skip operand in registers) and two workgroups per CU
     int imgw_max = std::max(1, (16 * 8) / PIX);
@@ -3323,9 +3635,40 @@ extern "C" int rp_nn_pack_conv32(rp_ctx *ctx, const float *w_dev, float *frag_de
 
 extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *frag_dev, const float *bias_dev, float *out_dev, int64_t B, int32_t Cin, int32_t H,
                                 int32_t W) {
-    if (!ctx || !x_dev || !frag_dev || !bias_dev || !out_dev || B < 0 || H < 1 || W < 1 || (Cin != 16 && Cin != 32) || H * W > (Cin == 16 ? 112 : 80))
-        return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: bad argument (Cin 16: <= 112 pixels, Cin 32: <= 80 pixels)");
+    if (!ctx || !x_dev || !frag_dev || !bias_dev || !out_dev || B < 0 || H < 1 || W < 1 || (Cin != 16 && Cin != 32) || H * W > (Cin == 16 ? 640 : 512))
+        return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: bad argument (Cin 16: <= 640 pixels, Cin 32: <= 512 pixels)");
     if (B == 0) return RP_OK;
+    if (H * W > (Cin == 16 ? 112 : 80)) {  // IMGW leaves per workgroup (k_convpool32_wg)
+        const int PIXw = H * W, max_nt = Cin == 16 ? 10 : 8;  // tile rows per workgroup in units of 64: 40 tiles (Cin 16) / 32 tiles (Cin 32)
+        const size_t img_px = (size_t)(H + 2) * (W + 2);
+        auto floats_of = [&](int k) { return (std::max<size_t>((k * img_px + 1) * Cin, (size_t)16 * ((k * PIXw + 15) / 16) * 36) + 3) & ~(size_t)3; };
+        int imgw = 0, nt = 0, waves = 4;
+        long long best = -1;
+        for (int k = 1; k * PIXw <= 64 * max_nt && floats_of(k) * sizeof(float) <= ctx->lds_per_cu; ++k) {
+            const int tk = (k * PIXw + 15) / 16, wk = tk > 16 ? 8 : 4, ntk = (tk + wk - 1) / wk;
+            const long long cost = wg_group_cost(B, k, wk * ntk, ctx->n_cu);
+            if (best < 0 || cost < best) { best = cost; imgw = k; nt = ntk; waves = wk; }
+        }
+        if (imgw == 0) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: a %dx%d image does not fit LDS", H, W);
+        const size_t wf = floats_of(imgw), lds = wf * sizeof(float);
+        const long long tasks = (B + imgw - 1) / imgw;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+        const dim3 grid((unsigned)std::min<long long>(tasks, (long long)ctx->n_cu * per_cu)), block(64 * waves);
+#define CPW_LAUNCH(NT_, CIN_, WV_)                                                                                                                   \
+    case (NT_ * 64 + CIN_) * 16 + WV_: {                                                                                                             \
+        const int rc_ = allow_lds(ctx, (const void *)k_convpool32_wg<NT_, CIN_, WV_>, lds, "rp_nn_convpool32"); if (rc_ != RP_OK) return rc_;        \
+        hipLaunchKernelGGL((k_convpool32_wg<NT_, CIN_, WV_>), grid, block, lds, ctx->stream, x_dev, frag_dev, bias_dev, out_dev, (long long)B,       \
+                           (int)H, (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                         \
+    } break;
+        switch ((nt * 64 + (int)Cin) * 16 + waves) {
+            CPW_LAUNCH(2, 16, 4) CPW_LAUNCH(3, 16, 4) CPW_LAUNCH(4, 16, 4) CPW_LAUNCH(3, 16, 8) CPW_LAUNCH(4, 16, 8) CPW_LAUNCH(5, 16, 8)
+            CPW_LAUNCH(2, 32, 4) CPW_LAUNCH(3, 32, 4) CPW_LAUNCH(4, 32, 4) CPW_LAUNCH(3, 32, 8) CPW_LAUNCH(4, 32, 8)
+            default: return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: unsupported image size");
+        }
+#undef CPW_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return RP_OK;
+    }
     const int PIX = H * W, max_tiles = Cin == 16 ? 7 : 5;
     const size_t img_pixels = (size_t)(H + 2) * (W + 2);
     int imgw = (16 * max_tiles) / PIX;
@@ -3367,10 +3710,38 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
 
 extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *frag4_dev, const float *bias4_dev, float *out_dev, float *out_relu_dev, int64_t B,
                                 int32_t H, int32_t W) {
-    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 80)
-        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: bad argument (images of at most 80 pixels)");
+    if (!ctx || !x_dev || !frag4_dev || !bias4_dev || !out_dev || B < 0 || H < 1 || W < 1 || H * W > 512)
+        return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: bad argument (images of at most 512 pixels)");
     if (B == 0) return RP_OK;
     const int PIX = H * W;
+    if (PIX > 80) {  // IMGW leaves per workgroup (k_resstage32_wg): the group size with the best fill of 4 waves x nt tiles x 16 rows
+        const size_t img_px = (size_t)(H + 2) * (W + 2);
+        auto lds_of = [&](int k) { return (128 + (k * img_px + 1) * 32) * sizeof(float); };
+        int imgw = 1, nt = 0, waves = 4;
+        long long best = -1;
+        for (int k = 1; k * PIX <= 512 && lds_of(k) <= ctx->lds_per_cu; ++k) {  // <= 32 tiles: 8 waves x 4 tiles
+            const int tk = (k * PIX + 15) / 16, wk = tk > 16 ? 8 : 4, ntk = (tk + wk - 1) / wk;
+            const long long cost = wg_group_cost(B, k, wk * ntk, ctx->n_cu);
+            if (best < 0 || cost < best) { best = cost; imgw = k; nt = ntk; waves = wk; }
+        }
+        if (nt == 0) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: a %dx%d image does not fit LDS", H, W);
+        const size_t lds = lds_of(imgw);
+        const long long tasks = (B + imgw - 1) / imgw;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+        const dim3 grid((unsigned)std::min<long long>(tasks, (long long)ctx->n_cu * per_cu)), block(64 * waves);
+#define RSW_LAUNCH(NT_, WV_)                                                                                                                        \
+    case NT_ * 16 + WV_: {                                                                                                                          \
+        const int rc_ = allow_lds(ctx, (const void *)k_resstage32_wg<NT_, WV_>, lds, "rp_nn_resstage32"); if (rc_ != RP_OK) return rc_;            \
+        hipLaunchKernelGGL((k_resstage32_wg<NT_, WV_>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
+    } break;
+        switch (nt * 16 + waves) {
+            RSW_LAUNCH(2, 4) RSW_LAUNCH(3, 4) RSW_LAUNCH(4, 4) RSW_LAUNCH(3, 8) RSW_LAUNCH(4, 8)
+            default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: unsupported image size");
+        }
+#undef RSW_LAUNCH
+        HIPCHK(ctx, hipGetLastError());
+        return RP_OK;
+    }
     const size_t img_pixels = (size_t)(H + 2) * (W + 2);
     auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + 128 + 4 * (k * img_pixels + 1) * 32) * sizeof(float); };
     int imgw_max = 80 / PIX;                                       // leaves per wave: at most 5 pixel tiles of 16
@@ -3419,11 +3790,32 @@ extern "C" int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out,
     return RP_OK;
 }
 
+static int launch_commit(rp_ctx *ctx, int rows, const float *pi_dev, const float *v_dev, bool logits) {
+    const DP &d = ctx->d;
+    const dim3 grid(grid_for(rows)), block(64 * WAVES_PER_BLOCK);
+    const size_t lds = logits ? (size_t)WAVES_PER_BLOCK * d.A * sizeof(float) : 0;
+    if (logits) {
+        if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
+        else hipLaunchKernelGGL((k_commit<u32, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
+    } else {
+        if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, false>), grid, block, 0, ctx->stream, d, pi_dev, v_dev);
+        else hipLaunchKernelGGL((k_commit<u32, false>), grid, block, 0, ctx->stream, d, pi_dev, v_dev);
+    }
+    hipError_t le_ = hipGetLastError();
+    if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of k_commit failed: %s", hipGetErrorString(le_));
+    return RP_OK;
+}
+
 extern "C" int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev) {
     if (!ctx || !pi_dev || !v_dev) return fail(ctx, RP_ERR_ARG, "rp_commit_eval: bad argument");
-    const DP &d = ctx->d;
-    DISPATCH(ctx, k_commit, grid_for(d.G), d, pi_dev, v_dev);
-    return RP_OK;
+    return launch_commit(ctx, ctx->d.G, pi_dev, v_dev, false);
+}
+
+extern "C" int rp_commit_eval_logits(rp_ctx *ctx, const float *logits_dev, const float *v_dev) {
+    if (!ctx || !logits_dev || !v_dev) return fail(ctx, RP_ERR_ARG, "rp_commit_eval_logits: bad argument");
+    if ((size_t)WAVES_PER_BLOCK * ctx->d.A * sizeof(float) > 24 * 1024)
+        return fail(ctx, RP_ERR_ARG, "rp_commit_eval_logits: %d actions do not fit the kernel's LDS row buffers (at most 1536): take the softmax first and call rp_commit_eval", ctx->d.A);
+    return launch_commit(ctx, ctx->d.G, logits_dev, v_dev, true);
 }
 
 extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows) {
@@ -3438,7 +3830,7 @@ extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const floa
     Scratch s(ctx);
     float *dpi = s.up(pi_host, (size_t)n * d.A); NEED(dpi);
     float *dv = s.up(v_host, (size_t)n); NEED(dv);
-    DISPATCH(ctx, k_commit, grid_for(n), d, (const float *)dpi, (const float *)dv);
+    { const int rc = launch_commit(ctx, n, dpi, dv, false); if (rc != RP_OK) return rc; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_device_error(ctx);
 }

@@ -46,13 +46,14 @@ class _Group:
             # relu(stem) is only read by the library path of stage 0; k_resstage16 takes x alone and applies the ReLU itself, so with
             # the stage kernels the engine is handed NULL and writes 6.4 KB per leaf instead of 12.8 (half of k_leaf_stem's HBM bytes)
             self.fused = bool(owner.fuse_elementwise)
-            stage0_kernel = owner.resblock_kernel and ((owner.H + 1) // 2) * ((owner.W + 1) // 2) <= 128
+            stage0_kernel = owner.resblock_kernel and ((owner.H + 1) // 2) * ((owner.W + 1) // 2) <= 640  # BinPackingNNet.STAGE16_MAX_PIXELS
             self.stem_relu = torch.zeros_like(self.stem) if (owner.fuse_elementwise and not stage0_kernel) else None
             self.planes = None
         else:
             self.planes = torch.zeros((games, owner.N + 1, owner.H, owner.W), dtype=torch.float32, device=owner.device)
         self.graph = None
         self.pi = self.v = None
+        self.raw_logits = False
 
     def refresh_weights(self, nnet):
         if self.use_stem:
@@ -62,10 +63,24 @@ class _Group:
             if self.fused and self.channels_last and self.resblock_kernel:
                 self._frag_src = nnet.nnet.refresh_frags(self.eng)
 
-    def forward(self, nnet):
+    def leaf_inputs(self):
+        """Evaluator input of the waiting leaves: the stem (first convolution + pool from the packed state) or the dense planes."""
         if self.use_stem:
-            return nnet.predict_from_stem(self.stem, self.stem_relu, self.eng if self.fused else None)
+            self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None, self.channels_last)
+        else:
+            self.eng.leaf_planes(self.planes.data_ptr(), self.G)
+
+    def forward(self, nnet):
+        """-> (policy rows, values).  With the fused evaluator the policy rows are the RAW logits and the softmax is taken inside the
+        commit kernel (rp_commit_eval_logits) when the action space fits its LDS row buffer."""
+        if self.use_stem:
+            self.raw_logits = self.fused and self.eng.A <= self.eng.LOGITS_MAX_ACTIONS
+            return nnet.predict_from_stem(self.stem, self.stem_relu, self.eng if self.fused else None, logits=self.raw_logits)
+        self.raw_logits = False
         return nnet.predict_batch(self.planes)
+
+    def commit(self, pi, v):
+        (self.eng.commit_eval_logits if self.raw_logits else self.eng.commit_eval)(pi.data_ptr(), v.data_ptr())
 
     def wave_eager(self, nnet):
         if self.host_evaluator is not None:  # generic evaluator on the host: leaf states out, (pi, v) back (like nnet.predict, MCTS_bpp.py:87)
@@ -76,12 +91,9 @@ class _Group:
                 self.eng.commit_eval_host(pi, v)
             return
         self.eng.search_step(sync=False)
-        if self.use_stem:
-            self.eng.leaf_stem(self.stem.data_ptr(), self.G, self.stem_relu.data_ptr() if self.stem_relu is not None else None, self.channels_last)
-        else:
-            self.eng.leaf_planes(self.planes.data_ptr(), self.G)
+        self.leaf_inputs()
         self.pi, self.v = self.forward(nnet)
-        self.eng.commit_eval(self.pi.data_ptr(), self.v.data_ptr())
+        self.commit(self.pi, self.v)
 
 
 class BatchedSelfPlay:

@@ -341,3 +341,52 @@ def test_c5_at_800_sims_matches_oracle_digest():
     assert digest == f["tree_sha256"]
     print("c5 at 800 sims: %d nodes, %d moves, arena peak %s" % (len(tree), int(moves[0]), eng.arena_peak()))
     eng.close()
+
+
+@pytest.mark.parametrize("W,H,N", [(10, 10, 8), (20, 20, 32), (33, 12, 9)])
+def test_commit_from_logits_equals_commit_from_softmax(W, H, N):
+    """rp_commit_eval_logits (the softmax of NNet.predict, NNet.py:81-85, taken inside the commit kernel) against rp_commit_eval fed
+    torch.softmax of the same logits: the same legal moves, expansion state and value backup; every prior P = pi / sum within float32
+    rounding of the softmax (1e-6 relative: the two differ in the order of the float32 sum); the uniform fallback (MCTS_bpp.py:93-100) cannot
+    be reached through a softmax and is not exercised here.  Action spaces beyond the kernel's LDS row buffer are refused."""
+    import torch
+    from resource_packing_self_play_amd import _lib
+    games, A = 48, W * N
+    rng = np.random.default_rng(W + N)
+    wh = np.stack([gen_items(rng, W, H, N) for _ in range(games)])
+    torch.manual_seed(W)
+    logits = (torch.randn(games, A, device="cuda") * 4.0).contiguous()
+    logits[3] = 0.0  # a flat row
+    logits[5, : A // 2] = -60.0  # probabilities that underflow to denormals / zero
+    v = torch.tanh(torch.randn(games, device="cuda")).contiguous()
+    trees = []
+    for mode in ("softmax", "logits"):
+        eng = make_engine(W, H, N, games, 4, move_rule=_lib.MOVE_EXTERNAL, stream=torch.cuda.current_stream().cuda_stream)
+        eng.begin_episodes(wh, np.full(games, W * H, np.int32))
+        assert eng.search_step() == games  # every root waits for the evaluator, row b = slot b
+        if mode == "softmax":
+            pi = torch.softmax(logits, dim=1).contiguous()
+            eng.commit_eval(pi.data_ptr(), v.data_ptr())
+        else:
+            eng.commit_eval_logits(logits.data_ptr(), v.data_ptr())
+        torch.cuda.synchronize()
+        ph, sd, _, _ = eng.status()
+        assert (ph == _lib.PHASE_RUNNING).all() and (sd == 1).all()
+        trees.append([tree_as_dict(eng.dump_tree(g)) for g in range(games)])
+        eng.close()
+    worst = 0.0
+    for g in range(games):
+        a, b = trees[0][g], trees[1][g]
+        assert a.keys() == b.keys() and len(a) == 1
+        for key in a:
+            ra, rb = a[key], b[key]
+            assert ra["expanded"] == rb["expanded"] == 1 and ra["ns"] == rb["ns"] == 0 and np.array_equal(ra["actions"], rb["actions"])
+            assert abs(ra["p"].sum() - 1.0) < 1e-12 and abs(rb["p"].sum() - 1.0) < 1e-12
+            rel = np.abs(ra["p"] - rb["p"]) / np.maximum(ra["p"], 1e-30)
+            worst = max(worst, float(rel[ra["p"] > 1e-30].max()))
+    print("%dx%d/%d: max relative difference of a prior, logits path vs torch.softmax path: %.2e" % (W, H, N, worst))
+    assert worst < 2e-6
+    big = make_engine(50, 50, 128, 1, 1, move_rule=_lib.MOVE_EXTERNAL)
+    with pytest.raises(_lib.EngineError):
+        big.commit_eval_logits(logits.data_ptr(), v.data_ptr())
+    big.close()

@@ -58,3 +58,16 @@ def test_dotdict_and_average_meter():
     assert a.numMCTSSims == 25 and a["cpuct"] == 1
     m = AverageMeter(); m.update(2.0, 2); m.update(4.0, 2)
     assert m.avg == 3.0 and m.count == 4
+
+
+def test_trim_min_equals_the_reference_loop():
+    """CoachBPP.trim_min against the literal `while len > cap: pop(argmin)` of CoachBPP.py:136-139, ties and NaN-free floats."""
+    from resource_packing_self_play_amd.CoachBPP import trim_min
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n, cap = int(rng.integers(0, 60)), int(rng.integers(1, 40))
+        vals = [float(v) for v in rng.choice([0.0, 0.25, 0.5, 0.8, 0.9, 1.0], size=n)] if trial % 2 else [float(v) for v in rng.uniform(0, 1, n)]
+        want = list(vals)
+        while len(want) > cap:
+            want.pop(int(np.argmin(want)))
+        assert trim_min(vals, cap) == want
