@@ -432,7 +432,7 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
                 vis_cap=vis_cap, groups=a.groups, use_graph=not a.no_graph, sample_seed=12345)
     gen = ItemsGenerator(W, H, N)
     coach = CoachBPP(game, nnet, gen.items_generator(100), W * H, gen, args, saved_rewards_list=list(rank_buffer()))
-    if world > 1:
+    if rdist.collectives_on():  # more than one rank, or a forced one-rank group (RP_DIST_FORCE=1: RCCL smoke run on one GPU)
         rdist.attach(nnet)
         nnet.grad_hook.timing = []
     coach.drawIteration = lambda: (H, list(range(100, 100 + n_eps)))  # the bench's instances: seeds 100 + global episode index, full-height rectangle

@@ -102,7 +102,7 @@ class CoachBPP:
         s = _opt(self.args, "sample_seed", None)
         if s is None:
             s = int.from_bytes(os.urandom(7), "little")
-            if rdist.world_size() > 1:
+            if rdist.collectives_on():
                 t = torch.tensor([s], dtype=torch.int64, device=self.nnet.device)
                 torch.distributed.broadcast(t, src=0)
                 s = int(t.item())
@@ -139,7 +139,7 @@ class CoachBPP:
         args = self.args
         np.random.seed()  # CoachBPP.py:117
         draw = [np.random.randint(args.binH_min, args.binH + 1)] + [np.random.randint(int(1e5)) for _ in range(args.numEps)]
-        if rdist.world_size() > 1:  # every rank must play the same instances
+        if rdist.collectives_on():  # every rank must play the same instances
             t = torch.tensor(draw, dtype=torch.int64, device=self.nnet.device)
             torch.distributed.broadcast(t, src=0)
             draw = t.cpu().tolist()
@@ -193,7 +193,7 @@ class CoachBPP:
             torch.cuda.synchronize(dev)
         t_play = time.time() - t0
         self.last_example_keys = replay.episode * (self.game.num_items + 1) + replay.move.to(torch.int64) - base * (self.game.num_items + 1)  # LOCAL examples (tests)
-        if rdist.world_size() > 1:
+        if rdist.collectives_on():
             mine_t = torch.as_tensor(mine, dtype=torch.int64, device=dev)
             gathered = rdist.all_gather_variable(torch.stack([mine_t.to(torch.float64), local], dim=1))
             ep_scores = np.zeros(n_eps)
@@ -213,7 +213,7 @@ class CoachBPP:
         import torch
         from .replay import PackedReplay
         args = self.args
-        if rdist.world_size() > 1 and getattr(self.nnet, "grad_hook", None) is None:
+        if rdist.collectives_on() and getattr(self.nnet, "grad_hook", None) is None:
             rdist.attach(self.nnet)  # identical weights on every rank, gradients summed over the ranks' batch slices
         for i in range(1, args.numIters + 1):
             log.info("Starting Iter #%d ...", i)

@@ -114,7 +114,7 @@ class NNetWrapper(NeuralNet):
         draw = np.random.randint
         if self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
             world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
-        if world > 1:
+        if world > 1 or (self.grad_hook is not None and os.environ.get("RP_DIST_FORCE") == "1"):
             seed = torch.tensor([np.random.randint(1 << 31) if rank == 0 else 0], dtype=torch.int64, device=device)
             torch.distributed.broadcast(seed, src=0)
             draw = np.random.RandomState(int(seed.item())).randint

@@ -1226,9 +1226,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     if (lane < p.N) { e0 = pe[lane]; n0 = pn[lane]; }
     if (lane + 64 < p.N) { e1 = pe[lane + 64]; n1 = pn[lane + 64]; }
     const float *row = pi + (size_t)b * p.A;
-    if (LOGITS) {  // the row's logits are requested with the slot's state
-        float *sp = s_soft + (size_t)wv * p.A;
-        for (int a = lane; a < p.A; a += 64) sp[a] = row[a];
+    constexpr int LPL = 24;  // logits per lane: A <= 1536 (rp_commit_eval_logits checks)
+    float xr[LOGITS ? LPL : 1];
+    if (LOGITS) {  // the row's logits are requested with the slot's state and stay in registers (-inf past the row: exp gives 0)
+#pragma unroll
+        for (int i = 0; i < LPL; ++i) { const int a = lane + 64 * i; xr[i] = (64 * i < p.A && a < p.A) ? row[a] : -INFINITY; }
     }
     if (uni(phase) != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
@@ -1238,16 +1240,19 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     if (lane + 64 < depth) t.backup_entry(n1, e1, v, RP_KIND_F32);
     if (LOGITS) {
         float *sp = s_soft + (size_t)wv * p.A;
-        wave_sync();
-        float m = -INFINITY;
-        for (int a = lane; a < p.A; a += 64) m = fmaxf(m, sp[a]);
+        float m = xr[0];
+#pragma unroll
+        for (int i = 1; i < LPL; ++i) m = fmaxf(m, xr[i]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         float sum = 0.f;
-        for (int a = lane; a < p.A; a += 64) { const float e = expf(sp[a] - m); sp[a] = e; sum += e; }
+#pragma unroll
+        for (int i = 0; i < LPL; ++i)
+            if (64 * i < p.A) { xr[i] = __expf(xr[i] - m); sum += xr[i]; }  // uniform: whole 64-wide groups past the row are skipped
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-        for (int a = lane; a < p.A; a += 64) sp[a] = sp[a] / sum;
+#pragma unroll
+        for (int i = 0; i < LPL; ++i) { const int a = lane + 64 * i; if (64 * i < p.A && a < p.A) sp[a] = xr[i] / sum; }
         wave_sync();
         row = sp;
     }

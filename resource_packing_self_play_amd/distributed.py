@@ -28,7 +28,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(base, "rank%d" % rank, "cache"))
         for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
             os.makedirs(os.environ[k], exist_ok=True)
-    if world > 1 and not dist.is_initialized():
+    # RP_DIST_FORCE=1: form the process group even for one rank (RCCL smoke run on a single-GPU box: backend initialisation and the
+    # device-tensor collectives are the same code at any world size)
+    if (world > 1 or os.environ.get("RP_DIST_FORCE") == "1") and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("RP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -40,6 +42,11 @@ def init_from_env(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def collectives_on():
+    """Collectives run when there is more than one rank -- or when a one-rank group was formed on purpose (RP_DIST_FORCE)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("RP_DIST_FORCE") == "1")
 
 
 def rank():
@@ -63,7 +70,7 @@ def _host_staged():
 
 def all_gather_variable(t):
     """All-gathers tensors that differ in their first dimension; returns the concatenation in rank order."""
-    if world_size() == 1:
+    if not collectives_on():
         return t
     dev = t.device
     if _host_staged():
@@ -90,7 +97,7 @@ def all_gather_examples(planes, pi, value):
 
 def all_gather_bytes(flat):
     """All-gathers one uint8 vector per rank (lengths differ); returns the list of every rank's vector in rank order."""
-    if world_size() == 1:
+    if not collectives_on():
         return [flat]
     dev = flat.device
     if _host_staged():
@@ -116,7 +123,7 @@ def all_gather_packed(replay):
     reference's order (episode by episode, move by move), identical on every rank."""
     import time
     from .replay import PackedReplay
-    if world_size() == 1:
+    if not collectives_on():
         last_exchange.update(bytes_sent=0, bytes_received=0, ms=0.0, examples=len(replay))
         return replay
     if replay.device.type == "cuda":
@@ -145,7 +152,7 @@ class FlatGradAllReduce:
 
     def __call__(self, module, extra=()):
         extra = tuple(extra)
-        if world_size() == 1:
+        if not collectives_on():
             return extra
         dev = self.params[0].device
         total = self.numel + len(extra)
@@ -181,7 +188,7 @@ class FlatGradAllReduce:
 
 
 def broadcast_parameters(module, src=0):
-    if world_size() == 1:
+    if not collectives_on():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)

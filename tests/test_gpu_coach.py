@@ -348,3 +348,17 @@ def test_sampling_streams_differ_between_iterations_and_repeat_for_a_pinned_seed
     c = play(1, sample_seed=None)
     d = play(1, sample_seed=None)
     assert not (c[0][1].shape == d[0][1].shape and np.array_equal(c[0][1], d[0][1])), "two unpinned Coaches drew the same moves"
+
+
+@pytest.mark.timeout(600)
+def test_rccl_backend_initialises_and_runs_every_collective_on_one_rank():
+    """backend "nccl" IS RCCL on ROCm.  A one-rank group on this box's GPU: init_from_env's nccl branch, all_gather_variable,
+    all_gather_packed (all_gather_into_tensor on device bytes), FlatGradAllReduce and broadcast_parameters on device tensors
+    (tests/rccl_worker.py).  More ranks need more GPUs: RCCL refuses two ranks on one device."""
+    with __import__("socket").socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RP_DIST_FORCE="1", RP_DIST_BACKEND="nccl")
+    p = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(HERE, "rccl_worker.py")], env=env, capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    print(p.stdout.strip().splitlines()[-1])
+    assert "rccl ok: backend nccl" in p.stdout
