@@ -488,7 +488,7 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=0, help="instances per step per GPU (default = games: every slot plays one episode)")
     ap.add_argument("--sims", type=int, default=0)
     ap.add_argument("--edge-factor", type=int, default=0, help="legal-move arena = node arena x this (6 B per entry; default: the configuration's)")
-    ap.add_argument("--vis-factor", type=float, default=1.5, help="visited-edge arena = node arena x this (26 B per entry)")
+    ap.add_argument("--vis-factor", type=float, default=1.5, help="visited-edge arena = node arena x this (32 B per entry)")
     ap.add_argument("--no-reclaim", action="store_true", help="keep dead levels' arena chunks (needs ~5x the arena)")
     ap.add_argument("--groups", type=int, default=1, help="slot groups per GPU, each with its own stream and graph; 3 co-schedules the groups' kernels "
                     "(+4 %% episodes/s) but then no kernel has the GPU to itself and per-kernel durations stop meaning anything")

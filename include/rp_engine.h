@@ -78,7 +78,7 @@ typedef struct rp_config {
     uint64_t seed;         /* RNG seed for RP_MOVE_SAMPLE and the tie rule */
     uint64_t tie_salt;     /* salt of the deterministic stand-in for np.random.choice([1,-1]) (BinPackingGame.py:212) */
     int32_t device;        /* HIP device ordinal */
-    int32_t vis_cap;       /* per-game visited-edge arena (26-byte entries); 0 = automatic */
+    int32_t vis_cap;       /* per-game visited-edge arena (32-byte entries); 0 = automatic */
     void *stream;          /* hipStream_t; NULL = the default stream */
     int64_t max_examples;  /* capacity of the replay buffer in examples; 0 = none recorded */
     int64_t max_sparse;    /* capacity of the replay buffer's pool of (action, visit count) pairs -- one per visited root edge of every
@@ -305,7 +305,7 @@ int rp_check(rp_ctx *ctx);
 /* Sizes of slot g's tree: nodes in use and the span of its legal-move arena (the index range of rp_dump_tree's edge arrays). */
 int rp_tree_size(rp_ctx *ctx, int32_t slot, int32_t *n_nodes_out, int32_t *n_edges_out);
 /* High-water marks of the level arenas over all slots since create: chunks in use (legal-move runs, visited blocks) and
- * the chunk sizes in entries (6 and 26 bytes per entry).  Sizing aid for edge_cap / vis_cap. */
+ * the chunk sizes in entries (6 and 32 bytes per entry).  Sizing aid for edge_cap / vis_cap. */
 int rp_arena_peak(rp_ctx *ctx, int32_t *prior_chunks_out, int32_t *visited_chunks_out, int32_t *chunk_entries_out2);
 /* Host copy of slot g's tree.  Node i: rows u64[H], remaining u8[N], term i8 (0 / +-1 = Es),
  * term_kind u8, expanded u8, ns u32, edge_off u32, n_valid u32.  Edge e (one per legal move, dense view of the sparse

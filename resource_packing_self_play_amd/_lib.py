@@ -491,7 +491,7 @@ class Engine:
         a, b = _i32(0), _i32(0)
         ce = (_i32 * 2)()
         self._ck(self.L.rp_arena_peak(self.h, C.byref(a), C.byref(b), ce))
-        return {"prior_chunks": a.value, "visited_chunks": b.value, "prior_bytes": a.value * ce[0] * 6, "visited_bytes": b.value * ce[1] * 26}
+        return {"prior_chunks": a.value, "visited_chunks": b.value, "prior_bytes": a.value * ce[0] * 6, "visited_bytes": b.value * ce[1] * 32}
 
     def tree_size(self, slot):
         a, b = _i32(0), _i32(0)

@@ -75,6 +75,16 @@ struct PoolDesc {
     const unsigned char *wh;  // [n_instances][N][2]
     const int *area, *max_h;
 };
+// A visited edge: one 32-byte record = two 16-byte loads.  (Five parallel arrays -- idx, N, child, Q, P -- cost a node with a few visited
+// edges five cache lines per selection and a backup two; the record costs one.)
+struct VisEntry {
+    double q;    // Qsa
+    double p;    // Ps[s][a] = float64(pi) / norm
+    u32 n;       // Nsa (low 30 bits) | kind of Q (top 2 bits)
+    u32 child;   // child node id (NONE32 until first traversed)
+    u32 idx;     // index into the node's legal-move run
+    u32 pad;
+};
 struct DP {  // device view of a context, passed by value to every kernel
     int W, H, N, A, G, sims, node_cap, edge_cap, vis_cap, table_cap, KW, RW, RMW, move_rule;
     int reclaim;   // 1: a level's legal-move runs and visited blocks are recycled once the root has moved past it
@@ -116,11 +126,7 @@ struct DP {  // device view of a context, passed by value to every kernel
     u32 *key;       // [G][node_cap][KW]
     u16 *pAct;      // [G][edge_cap]  legal moves of every node, ascending action
     float *pPi;     // [G][edge_cap]  evaluator probability of that move (NNet.predict's pi, float32)
-    u16 *vIdx;      // [G][vis_cap]   visited edges: index into the node's legal-move run
-    u32 *vN;        //                Nsa (low 30 bits) | kind of Q (top 2 bits)
-    double *vQ;     //                Qsa
-    double *vP;     //                Ps[s][a] = float64(pi) / norm
-    u32 *vChild;    //                child node id (NONE32 until first traversed)
+    VisEntry *vis;  // [G][vis_cap]   visited edges
     u64 *table;     // [G][table_cap]  (tag << 32) | (node id + 1), 0 = empty
     // NumPy pairwise-sum plan over A elements, carried in the kernel arguments (scalar loads)
     int n_leaves;
@@ -497,9 +503,7 @@ template <typename row_t, bool BIG = true> struct Tree {
     u32 *key;
     u16 *pAct;
     float *pPi;
-    u16 *vIdx;
-    u32 *vN, *vChild;
-    double *vQ, *vP;
+    VisEntry *vis;
     u64 *table;
     const u8 *wh;
     Arena pa, va;  // legal-move runs, visited blocks
@@ -514,7 +518,7 @@ template <typename row_t, bool BIG = true> struct Tree {
         hdr = slot_region(p, p.hdr, g);
         key = slot_region(p, p.key, g);
         pAct = slot_region(p, p.pAct, g); pPi = slot_region(p, p.pPi, g);
-        vIdx = slot_region(p, p.vIdx, g); vN = slot_region(p, p.vN, g); vQ = slot_region(p, p.vQ, g); vP = slot_region(p, p.vP, g); vChild = slot_region(p, p.vChild, g);
+        vis = slot_region(p, p.vis, g);
         table = slot_region(p, p.table, g);
         wh = p.item_wh + (size_t)g * p.N * 2;
         n_nodes = p.n_nodes[g];
@@ -713,7 +717,7 @@ template <typename row_t, bool BIG = true> struct Tree {
         myrow = apply_move_rows<row_t>(myrow, p.H, p.W, j, iw, ih);
         if (!BIG || i < 64) rem0 &= ~(1ull << (i & 63)); else rem1 &= ~(1ull << (i - 64));
         u32 child = find_or_materialize(myrow, rem0, rem1, was_new);
-        if (lane_id() == 0 && child != NONE32 && e != NONE32) vChild[e] = child;
+        if (lane_id() == 0 && child != NONE32 && e != NONE32) vis[e].child = child;
         return child;
     }
     // Ps[s][a] of a legal move from the stored float32 pi and the node's normaliser (MCTS_bpp.py:89-100)
@@ -734,7 +738,10 @@ template <typename row_t, bool BIG = true> struct Tree {
         arena_commit(va, hd.depth, cap);
         for (u32 j = lane_id(); j < hd.vis_n; j += 64) {
             u32 s = hd.vis_off + j, d = dst + j;
-            vIdx[d] = vIdx[s]; vN[d] = vN[s]; vQ[d] = vQ[s]; vP[d] = vP[s]; vChild[d] = vChild[s];
+            const uint4 *src = (const uint4 *)(vis + s);
+            const uint4 a = src[0], b = src[1];
+            uint4 *dst4 = (uint4 *)(vis + d);
+            dst4[0] = a; dst4[1] = b;
         }
         hd.vis_off = dst; hd.vis_cap = (u16)cap;
         if (lane_id() == 0) { hdr[node].vis_off = dst; hdr[node].vis_cap = (u16)cap; }
@@ -747,8 +754,9 @@ template <typename row_t, bool BIG = true> struct Tree {
         if (hd.vis_n == hd.vis_cap && !grow_visited(node, hd)) return NONE32;
         const u32 e = hd.vis_off + hd.vis_n;
         if (lane_id() == 0) {
-            vIdx[e] = (u16)k; vN[e] = 0u; vQ[e] = 0.0; vChild[e] = NONE32;
-            vP[e] = prior_of(pi, hd.norm, (hd.flags & HF_FALLBACK) != 0);
+            VisEntry v;
+            v.q = 0.0; v.p = prior_of(pi, hd.norm, (hd.flags & HF_FALLBACK) != 0); v.n = 0u; v.child = NONE32; v.idx = k; v.pad = 0u;
+            vis[e] = v;
             hdr[node].vis_n = (u16)(hd.vis_n + 1);
         }
         hd.vis_n++;
@@ -778,11 +786,13 @@ template <typename row_t, bool BIG = true> struct Tree {
             for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
             wave_sync();
             for (u32 j = lane; j < hd.vis_n; j += 64) {
-                u32 e = hd.vis_off + j, k = vIdx[e];
+                const u32 e = hd.vis_off + j;
+                const VisEntry v = vis[e];  // two 16-byte loads; the child link rides along: no extra round trip after the argmax
+                const u32 k = v.idx;
                 atomicOr(&vmask[k >> 5], 1u << (k & 31));
-                u32 nn = vN[e] & NSA_MASK, ch = vChild[e];  // the child link rides along: no extra round trip after the argmax
-                double cp = p.cpuct * vP[e];
-                double u = nn ? vQ[e] + cp * s_vis / (double)(1u + nn) : cp * s_new;
+                u32 nn = v.n & NSA_MASK, ch = v.child;
+                double cp = p.cpuct * v.p;
+                double u = nn ? v.q + cp * s_vis / (double)(1u + nn) : cp * s_new;
                 if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; best_a = -1; }
             }
             wave_sync();
@@ -827,19 +837,19 @@ template <typename row_t, bool BIG = true> struct Tree {
         u32 found = NONE32;
         for (u32 jb = 0; jb < hd.vis_n; jb += 64) {
             u32 j = jb + lane_id();
-            u64 b = __ballot(j < hd.vis_n && vIdx[hd.vis_off + (j < hd.vis_n ? j : 0)] == (u16)k);
+            u64 b = __ballot(j < hd.vis_n && vis[hd.vis_off + (j < hd.vis_n ? j : 0)].idx == k);
             if (b) { found = hd.vis_off + jb + (__ffsll((long long)b) - 1); break; }
         }
         return found;
     }
     // one lane per path entry (MCTS_bpp.py:130-138)
     __device__ void backup_entry(u32 node, u32 e, double v, u32 vkind) {
-        u32 nn = vN[e];
+        u32 nn = vis[e].n;
         u32 cnt = nn & NSA_MASK, kind = nn >> 30;
-        double q = vQ[e];
+        double q = vis[e].q;
         q_update(q, kind, cnt, v, vkind);
-        vQ[e] = q;
-        vN[e] = (kind << 30) | (cnt + 1u);
+        vis[e].q = q;
+        vis[e].n = (kind << 30) | (cnt + 1u);
         hdr[node].ns += 1u;
     }
 };
@@ -871,7 +881,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &roo
     } else if (p.move_rule == RP_MOVE_ARGMAX_FIRST) {  // most visited, lowest action among equals
         u32 best_n = 0, best_k = NONE32, best_e = NONE32;
         for (u32 j = lane; j < hd.vis_n; j += 64) {
-            u32 e = hd.vis_off + j, n = t.vN[e] & NSA_MASK, k = t.vIdx[e];
+            u32 e = hd.vis_off + j, n = t.vis[e].n & NSA_MASK, k = t.vis[e].idx;
             if (n > best_n || (n == best_n && n > 0 && k < best_k)) { best_n = n; best_k = k; best_e = e; }
         }
 #pragma unroll
@@ -882,7 +892,7 @@ __device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &roo
         chosen = best_n ? best_e : NONE32;
     } else {  // RP_MOVE_SAMPLE: a ~ counts; inverse CDF in ascending action order over the (unordered) visited block
         u64 total = 0;
-        for (u32 j = lane; j < hd.vis_n; j += 64) total += t.vN[hd.vis_off + j] & NSA_MASK;
+        for (u32 j = lane; j < hd.vis_n; j += 64) total += t.vis[hd.vis_off + j].n & NSA_MASK;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) total += __shfl_xor(total, o);
         if (total) {
@@ -892,11 +902,11 @@ __device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &roo
                 u32 j = jb + lane;
                 bool act = j < hd.vis_n;
                 u32 e = hd.vis_off + (act ? j : 0);
-                u32 k = t.vIdx[e];
-                u64 n = act ? (u64)(t.vN[e] & NSA_MASK) : 0ull, below = 0;
+                u32 k = t.vis[e].idx;
+                u64 n = act ? (u64)(t.vis[e].n & NSA_MASK) : 0ull, below = 0;
                 for (u32 i = 0; i < hd.vis_n; ++i) {  // counts of all lower actions (uniform loads)
                     u32 e2 = hd.vis_off + i;
-                    if (t.vIdx[e2] < k) below += t.vN[e2] & NSA_MASK;
+                    if (t.vis[e2].idx < k) below += t.vis[e2].n & NSA_MASK;
                 }
                 u64 b = __ballot(act && n > 0 && below <= r && r < below + n);
                 if (b) chosen = hd.vis_off + jb + (__ffsll((long long)b) - 1);
@@ -908,8 +918,8 @@ __device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &roo
         return;
     }
     wave_sync();
-    const int chosen_action = chosen != NONE32 ? (int)t.pAct[hd.prior_off + t.vIdx[chosen]] : free_action;
-    u32 child = chosen != NONE32 ? t.vChild[chosen] : NONE32;
+    const int chosen_action = chosen != NONE32 ? (int)t.pAct[hd.prior_off + t.vis[chosen].idx] : free_action;
+    u32 child = chosen != NONE32 ? t.vis[chosen].child : NONE32;
     if (child == NONE32) {
         bool was_new;
         child = t.resolve_child(root, chosen, chosen_action, &was_new);
@@ -932,8 +942,8 @@ __device__ void play_move_impl(const DP &p, Tree<row_t, BIG> &t, int g, u32 &roo
                 if (lane == 0) { p.ex_sp_act[sp] = (u16)chosen_action; p.ex_sp_cnt[sp] = 1u; }
             } else {
                 for (u32 q = lane; q < n_sp; q += 64) {
-                    p.ex_sp_act[sp + q] = t.pAct[hd.prior_off + t.vIdx[hd.vis_off + q]];
-                    p.ex_sp_cnt[sp + q] = t.vN[hd.vis_off + q] & NSA_MASK;
+                    p.ex_sp_act[sp + q] = t.pAct[hd.prior_off + t.vis[hd.vis_off + q].idx];
+                    p.ex_sp_cnt[sp + q] = t.vis[hd.vis_off + q].n & NSA_MASK;
                 }
             }
             if (lane == 0) {
@@ -1248,7 +1258,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < LPL; ++i)
-            if (64 * i < p.A) { xr[i] = __expf(xr[i] - m); sum += xr[i]; }  // uniform: whole 64-wide groups past the row are skipped
+            if (64 * i < p.A) { xr[i] = expf(xr[i] - m); sum += xr[i]; }  // uniform: whole 64-wide groups past the row are skipped
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
 #pragma unroll
@@ -1649,9 +1659,8 @@ __global__ void k_root_counts(DP p, int first, int count, u32 *out) {
     if (root == NONE32) return;
     NodeHdr hd = slot_region(p, p.hdr, g)[root];
     const u16 *act = slot_region(p, p.pAct, g) + hd.prior_off;
-    const u16 *vi = slot_region(p, p.vIdx, g) + hd.vis_off;
-    const u32 *vn = slot_region(p, p.vN, g) + hd.vis_off;
-    for (u32 j = lane; j < hd.vis_n; j += 64) o[act[vi[j]]] = vn[j] & NSA_MASK;
+    const VisEntry *ve = slot_region(p, p.vis, g) + hd.vis_off;
+    for (u32 j = lane; j < hd.vis_n; j += 64) o[act[ve[j].idx]] = ve[j].n & NSA_MASK;
 }
 
 template <typename row_t>
@@ -3153,15 +3162,13 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         size_t off = 0;
         auto region = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_hdr = region((size_t)d.node_cap * sizeof(NodeHdr)), o_table = region((size_t)d.table_cap * 8);
-        const size_t o_vIdx = region((size_t)d.vis_cap * 2), o_vN = region((size_t)d.vis_cap * 4), o_vChild = region((size_t)d.vis_cap * 4);
-        const size_t o_vQ = region((size_t)d.vis_cap * 8), o_vP = region((size_t)d.vis_cap * 8);
+        const size_t o_vis = region((size_t)d.vis_cap * sizeof(VisEntry));
         const size_t o_key = region((size_t)d.node_cap * d.KW * 4), o_pAct = region((size_t)d.edge_cap * 2), o_pPi = region((size_t)d.edge_cap * 4);
         d.slab_stride = off;
         u8 *slab = nullptr;
         A_(slab, G * d.slab_stride);
         d.hdr = (NodeHdr *)(slab + o_hdr); d.table = (u64 *)(slab + o_table);
-        d.vIdx = (u16 *)(slab + o_vIdx); d.vN = (u32 *)(slab + o_vN); d.vChild = (u32 *)(slab + o_vChild);
-        d.vQ = (double *)(slab + o_vQ); d.vP = (double *)(slab + o_vP);
+        d.vis = (VisEntry *)(slab + o_vis);
         d.key = (u32 *)(slab + o_key); d.pAct = (u16 *)(slab + o_pAct); d.pPi = (float *)(slab + o_pPi);
     }
     A_(d.pa_cur, G * (N + 1)); A_(d.pa_head, G * (N + 1)); A_(d.pa_used, G * (N + 1)); A_(d.pa_next, G * d.n_pchunks); A_(d.pa_stack, G * d.n_pchunks); A_(d.pa_tf, G * 2);
@@ -3197,7 +3204,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
         for (void *p : ctx->allocs) (void)hipFree(p);
         delete ctx;
         return fail(nullptr, rc, "rp_create: %s (needs about %.1f GiB of HBM)", msg.c_str(),
-                    (double)(G * ((size_t)d.node_cap * (32 + 4 * d.KW) + (size_t)d.edge_cap * 6 + (size_t)d.vis_cap * 26 + (size_t)d.table_cap * 8)) / (1 << 30));
+                    (double)(G * ((size_t)d.node_cap * (32 + 4 * d.KW) + (size_t)d.edge_cap * 6 + (size_t)d.vis_cap * sizeof(VisEntry) + (size_t)d.table_cap * 8)) / (1 << 30));
     }
     // no chunk is open before the first episode begins
     (void)hipMemsetAsync(d.pa_cur, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream); (void)hipMemsetAsync(d.pa_head, 0xFF, G * (N + 1) * sizeof(u16), ctx->stream);
@@ -4147,19 +4154,15 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
     if (rc != RP_OK) return rc;
     const int nv = d.vis_cap;
     std::vector<NodeHdr> hdr(nn);
-    std::vector<u32> key((size_t)nn * d.KW), vN(nv), vC(nv);
-    std::vector<u16> vI(nv);
+    std::vector<u32> key((size_t)nn * d.KW);
+    std::vector<VisEntry> vis(nv);
     std::vector<float> pi(ne);
-    std::vector<double> vQ(nv), vP(nv);
+
     HIPCHK(ctx, hipMemcpy(hdr.data(), slot_region(d, d.hdr, slot), (size_t)nn * sizeof(NodeHdr), hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(key.data(), slot_region(d, d.key, slot), (size_t)nn * d.KW * 4, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(edge_action, slot_region(d, d.pAct, slot), (size_t)ne * 2, hipMemcpyDeviceToHost));
     HIPCHK(ctx, hipMemcpy(pi.data(), slot_region(d, d.pPi, slot), (size_t)ne * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vI.data(), slot_region(d, d.vIdx, slot), (size_t)nv * 2, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vN.data(), slot_region(d, d.vN, slot), (size_t)nv * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vC.data(), slot_region(d, d.vChild, slot), (size_t)nv * 4, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vQ.data(), slot_region(d, d.vQ, slot), (size_t)nv * 8, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(vP.data(), slot_region(d, d.vP, slot), (size_t)nv * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(vis.data(), slot_region(d, d.vis, slot), (size_t)nv * sizeof(VisEntry), hipMemcpyDeviceToHost));
     for (int i = 0; i < nn; ++i) {
         const NodeHdr &h = hdr[i];
         const u32 *k = key.data() + (size_t)i * d.KW;
@@ -4177,9 +4180,9 @@ extern "C" int rp_dump_tree(rp_ctx *ctx, int32_t slot, uint64_t *node_rows, uint
             edge_q[e] = 0.0; edge_nsa[e] = 0; edge_q_kind[e] = 0; edge_child[e] = NONE32;
         }
         for (u32 j = 0; j < h.vis_n; ++j) {
-            u32 v = h.vis_off + j, e = h.prior_off + vI[v];
-            if (edge_p[e] != vP[v]) return fail(ctx, RP_ERR_STATE, "rp_dump_tree: stored prior of a visited edge differs from pi / norm");
-            edge_q[e] = vQ[v]; edge_nsa[e] = vN[v] & NSA_MASK; edge_q_kind[e] = (u8)(vN[v] >> 30); edge_child[e] = vC[v];
+            u32 v = h.vis_off + j, e = h.prior_off + vis[v].idx;
+            if (edge_p[e] != vis[v].p) return fail(ctx, RP_ERR_STATE, "rp_dump_tree: stored prior of a visited edge differs from pi / norm");
+            edge_q[e] = vis[v].q; edge_nsa[e] = vis[v].n & NSA_MASK; edge_q_kind[e] = (u8)(vis[v].n >> 30); edge_child[e] = vis[v].child;
         }
     }
     return RP_OK;
