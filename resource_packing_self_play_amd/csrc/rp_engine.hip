@@ -198,6 +198,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+// The same for data a wave exchanges with itself through LDS only (the stage kernels' images and staging rows): LDS operations of one
+// wave execute in order, so nothing has to be waited for -- the wavefront-scope fence only keeps the compiler from moving LDS accesses
+// across the point.  wave_sync()'s workgroup fence is an s_waitcnt vmcnt(0) as well: in a persistent MFMA kernel that parks the wave
+// until its prefetched next input has arrived from HBM and its output stores have drained, four times per task.
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// Workgroup barrier for LDS traffic only: every wave's LDS operations have completed (lgkmcnt), then s_barrier.  __syncthreads() also
+// waits for the wave's global loads and stores (vmcnt(0)), which a persistent kernel wants to keep in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ u64 lanes_below() { return (1ull << lane_id()) - 1ull; }
 __device__ __forceinline__ u64 wave_xor_u64(u64 v) {
 #pragma unroll
@@ -1221,20 +1234,24 @@ template <typename row_t, bool LOGITS>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const float *pi, const float *vv) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
-    __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
-    extern __shared__ float s_soft[];  // LOGITS: [WAVES_PER_BLOCK][A]
-    const int b = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id(), wv = wave_in_block();
-    if (b >= (p.rows_identity ? p.G : *p.eval_count)) return;
-    const int g = __builtin_amdgcn_readfirstlane(p.rows_identity ? b : p.eval_slot[b]);
-    // everything that depends on the slot only is requested together (one memory round trip): phase, leaf, path, the value
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [WAVES_PER_BLOCK][min(A, TERM_CHUNK)] float64 terms, then (LOGITS) [WAVES_PER_BLOCK][A] floats
+    const int g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id(), wv = wave_in_block();
+    if (g >= p.G) return;
+    const int tchunk = p.A < TERM_CHUNK ? p.A : TERM_CHUNK;
+    double *s_term_w = s_dyn + (size_t)wv * tchunk;
+    float *s_soft = (float *)(s_dyn + (size_t)WAVES_PER_BLOCK * tchunk);
+    // One wave per SLOT: the slot's phase, leaf, path and evaluator row are requested together (one memory round trip) -- a wave per
+    // evaluator ROW first had to fetch the row's slot (eval_slot[b]) and only then the slot's state.  Slots that wait for nothing leave.
     const int phase = p.phase[g];
     const u32 node = p.leaf_node[g];
     const int depth = p.path_len[g];
-    const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
+    const int b = uni(p.rows_identity ? g : p.game_row[g]);  // k_compact wrote it for exactly the slots that wait in this wave
     const u32 *pe = p.path_edge + (size_t)g * p.N, *pn = p.path_node + (size_t)g * p.N;
     u32 e0 = 0, n0 = 0, e1 = 0, n1 = 0;  // path entries of levels lane and 64 + lane (entries past `depth` are stale and unused)
     if (lane < p.N) { e0 = pe[lane]; n0 = pn[lane]; }
     if (lane + 64 < p.N) { e1 = pe[lane + 64]; n1 = pn[lane + 64]; }
+    if (uni(phase) != RP_PHASE_WAIT_EVAL) return;
+    const double v = (double)vv[b];  // float32 array of shape (1,) (NNet.py:85)
     const float *row = pi + (size_t)b * p.A;
     constexpr int LPL = 24;  // logits per lane: A <= 1536 (rp_commit_eval_logits checks)
     float xr[LOGITS ? LPL : 1];
@@ -1242,7 +1259,6 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
 #pragma unroll
         for (int i = 0; i < LPL; ++i) { const int a = lane + 64 * i; xr[i] = (64 * i < p.A && a < p.A) ? row[a] : -INFINITY; }
     }
-    if (uni(phase) != RP_PHASE_WAIT_EVAL) return;
     Tree<row_t> t(p, g);
     NodeHdr hd = t.load_hdr(uni(node));
     // backup along the stored path (:130-139) first: its loads travel with the header's
@@ -1267,7 +1283,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
         row = sp;
     }
     bool fb;
-    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term[wv], &fb);
+    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term_w, &fb);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
         hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
         t.hdr[node] = hd;
@@ -2215,12 +2231,12 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
             float *d = img0 + ptab[e4 >> 2] + 4 * (e4 & 3);
             d[0] = fmaxf(v.x, 0.f); d[1] = fmaxf(v.y, 0.f); d[2] = fmaxf(v.z, 0.f); d[3] = fmaxf(v.w, 0.f);
         }
-        wave_sync();
+        lds_sync();
         rb_conv_all<0>(img0, bf0, bias0v, PW, PIX, ptab, ntiles_all, img1, nullptr, nullptr, nullptr);
-        wave_sync();
+        lds_sync();
         rb_conv_all<1>(img1, bf1, bias1v, PW, PIX, ptab, ntiles_all, nullptr, xl, out + (size_t)leaf * PIX * 16,
                        out_relu ? out_relu + (size_t)leaf * PIX * 16 : nullptr);
-        wave_sync();
+        lds_sync();
     }
 }
 
@@ -2257,6 +2273,13 @@ __global__ void __launch_bounds__(256) k_resblock16(const float *x, const float 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 rs_load_b(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+// activations stream through once: RS_STREAM_AUX = 2 marks their loads and stores non-temporal (experiment knob, default off)
+#ifndef RS_STREAM_AUX
+#define RS_STREAM_AUX 0
+#endif
+__device__ __forceinline__ f32x4 rs_load_x(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, RS_STREAM_AUX));
 }
 // One 3x3 convolution 16 -> 16 over NT pixel tiles.  wq: weight fragments of taps (tap, tap + 1) on entry -- taps 0 and 1 of the NEXT
 // convolution (byte offset fnext) on exit.
@@ -2336,7 +2359,7 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     auto load_x = [&](long long l0) {  // request a task's x in accumulator layout, zeros past its end
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * 16), 0, task_bytes(l0), RS_BUF_FLAGS);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) xv[t] = rs_load_b(rs, rowoff, t * 1024);
+        for (int t = 0; t < NT; ++t) xv[t] = rs_load_x(rs, rowoff, t * 1024);
     };
     auto stage_x = [&]() {  // xs = x (skip operand of block 0); relu(x) into the padded images
 #pragma unroll
@@ -2361,37 +2384,37 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
         const bool want_relu = out_relu != nullptr;
 #endif
         f32x4 acc[NT];
-        wave_sync();
+        lds_sync();
         RS_T(1)
         rs_conv<NT>(img, frs, 0, 9 * 1024, PW, abase, acc, wq);              // block 0, conv0
         RS_T(2)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[0]);
-        wave_sync();
+        lds_sync();
         RS_T(3)
         rs_conv<NT>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq);      // block 0, conv1 (+ skip x)
         RS_T(4)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { xs[t] = (acc[t] + bias4[1]) + xs[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // y1, kept as block 1's skip operand
-        wave_sync();
+        lds_sync();
         RS_T(5)
         rs_conv<NT>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq);     // block 1, conv0
         RS_T(6)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[2]);
-        wave_sync();
+        lds_sync();
         RS_T(7)
         rs_conv<NT>(img, frs, 27 * 1024, 0, PW, abase, acc, wq);             // block 1, conv1 (+ skip y1)
         RS_T(8)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = (acc[t] + bias4[3]) + xs[t];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, t * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, t * 1024, RS_STREAM_AUX);
         }
         if (want_relu) {  // uniform: relu(result) for the next layer's input, a second set of 16-byte stores
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * 16), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, t * 1024, 0);
+            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, t * 1024, RS_STREAM_AUX);
         }
         RS_T(9)
         // the image is free (the last convolution has read it): stage the next task, request the one after
@@ -2518,7 +2541,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
     auto load_x = [&](long long l0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * CIN), 0, task_bytes(l0), RS_BUF_FLAGS);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { xv[t][0] = rs_load_b(rs, rowoff, t * 2048); xv[t][1] = rs_load_b(rs, rowoff, t * 2048 + 64); }
+        for (int t = 0; t < NT; ++t) { xv[t][0] = rs_load_x(rs, rowoff, t * 2048); xv[t][1] = rs_load_x(rs, rowoff, t * 2048 + 64); }
     };
     auto stage_x = [&]() {
 #pragma unroll
@@ -2536,14 +2559,14 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
         f32x4 acc[NT][2];
 #define R32_BIAS(k) const f32x4 ba = *(const f32x4 *)(sbias + 32 * (k) + 4 * g), bb = *(const f32x4 *)(sbias + 32 * (k) + 16 + 4 * g)
-        wave_sync();
+        lds_sync();
         r32_conv<NT, CIN>(img, frs, 0, CONV_BYTES, PW, abase, acc, wq);                     // block 0, conv0
         {
             R32_BIAS(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
         }
-        wave_sync();
+        lds_sync();
         r32_conv<NT, CIN>(img, frs, CONV_BYTES, 2 * CONV_BYTES, PW, abase, acc, wq);        // block 0, conv1 (+ skip x)
         {
             R32_BIAS(1);
@@ -2553,22 +2576,22 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
                 *(f32x4 *)(img + pdst[t][0]) = rs_relu(xs[t][0]); *(f32x4 *)(img + pdst[t][1]) = rs_relu(xs[t][1]);
             }
         }
-        wave_sync();
+        lds_sync();
         r32_conv<NT, CIN>(img, frs, 2 * CONV_BYTES, 3 * CONV_BYTES, PW, abase, acc, wq);    // block 1, conv0
         {
             R32_BIAS(2);
 #pragma unroll
             for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
         }
-        wave_sync();
+        lds_sync();
         r32_conv<NT, CIN>(img, frs, 3 * CONV_BYTES, 0, PW, abase, acc, wq);                 // block 1, conv1 (+ skip y1)
         {
             R32_BIAS(3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t][0] = (acc[t][0] + ba) + xs[t][0]; acc[t][1] = (acc[t][1] + bb) + xs[t][1];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, t * 2048, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, t * 2048 + 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, t * 2048, RS_STREAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, t * 2048 + 64, RS_STREAM_AUX);
             }
         }
 #undef R32_BIAS
@@ -2576,8 +2599,8 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, t * 2048, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, t * 2048 + 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, t * 2048, RS_STREAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, t * 2048 + 64, RS_STREAM_AUX);
             }
         }
         if (leaf0 + stride_leaves < B) {
@@ -2642,7 +2665,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < XQ; ++q) xv[t][q] = rs_load_b(rs, rowoff, t * 16 * CIN * 4 + 64 * q);
+            for (int q = 0; q < XQ; ++q) xv[t][q] = rs_load_x(rs, rowoff, t * 16 * CIN * 4 + 64 * q);
     };
     const int cq = lane & 7;
     load_x(leaf0);
@@ -2656,9 +2679,9 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = xv[t][q];
         if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
         f32x4 acc[NT][2];
-        wave_sync();
+        lds_sync();
         r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
-        wave_sync();
+        lds_sync();
         // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows; rows past the
         // wave's pixels land behind the last real row (inside the wave's region: wave_floats covers 16 * NT rows)
 #pragma unroll
@@ -2666,7 +2689,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             *(f32x4 *)(img + m_row[t] * 36 + 4 * g) = acc[t][0] + ba;
             *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
         }
-        wave_sync();
+        lds_sync();
         // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table.  Branch-free: a neighbour outside
         // the image reads the centre again (max with itself), so all nine 16-byte reads of a window are in flight together
         float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
@@ -2684,7 +2707,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)), fmaxf(fmaxf(v4.w, v5.w), fmaxf(fmaxf(v6.w, v7.w), v8.w)));
             o4[pq * 8 + cq] = m;
         }
-        wave_sync();
+        lds_sync();
         if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
             float4 *z4 = (float4 *)img;
             for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2730,41 +2753,41 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage16_wg(const float *__res
     const int rowoff = n * 64 + g * 16, tile0 = wv * NT;
     f32x4 xs[NT], wq[3];
     wq[0] = rs_load_b(frs, lane * 16, 0); wq[1] = rs_load_b(frs, lane * 16, 1024);
-    __syncthreads();
+    lds_barrier();
     for (long long leaf = blockIdx.x; leaf < B; leaf += gridDim.x) {
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { xs[t] = rs_load_b(xrs, rowoff, (tile0 + t) * 1024); *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // zeros past the image
+        for (int t = 0; t < NT; ++t) { xs[t] = rs_load_x(xrs, rowoff, (tile0 + t) * 1024); *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // zeros past the image
         f32x4 acc[NT];
-        __syncthreads();
+        lds_barrier();
         rs_conv<NT>(img, frs, 0, 9 * 1024, PW, abase, acc, wq);              // block 0, conv0
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[0]);
-        __syncthreads();
+        lds_barrier();
         rs_conv<NT>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq);      // block 0, conv1 (+ skip x)
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < NT; ++t) { xs[t] = (acc[t] + bias4[1]) + xs[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }
-        __syncthreads();
+        lds_barrier();
         rs_conv<NT>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq);     // block 1, conv0
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[2]);
-        __syncthreads();
+        lds_barrier();
         rs_conv<NT>(img, frs, 27 * 1024, 0, PW, abase, acc, wq);             // block 1, conv1 (+ skip y1)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = (acc[t] + bias4[3]) + xs[t];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, (tile0 + t) * 1024, 0);  // dropped past the image
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, (tile0 + t) * 1024, RS_STREAM_AUX);  // dropped past the image
         }
         if (out_relu != nullptr) {
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf * PIX * 16), 0, PIX * 64, RS_BUF_FLAGS);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, (tile0 + t) * 1024, 0);
+            for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, (tile0 + t) * 1024, RS_STREAM_AUX);
         }
-        __syncthreads();  // every wave has read the image: the next task may overwrite it
+        lds_barrier();  // every wave has read the image: the next task may overwrite it
     }
 }
 
@@ -2802,7 +2825,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
     f32x4 xs[NT][2], wq[3][2];
     wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
     wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
-    __syncthreads();
+    lds_barrier();
     const long long stride_leaves = (long long)gridDim.x * IMGW;
     for (long long leaf0 = (long long)blockIdx.x * IMGW; leaf0 < B; leaf0 += stride_leaves) {
         const int nbytes = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW) * PIX * 128;
@@ -2812,22 +2835,22 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                xs[t][mt] = rs_load_b(xrs, rowoff, (tile0 + t) * 2048 + 64 * mt);
+                xs[t][mt] = rs_load_x(xrs, rowoff, (tile0 + t) * 2048 + 64 * mt);
                 *(f32x4 *)(img + pdst[t][mt]) = rs_relu(xs[t][mt]);
             }
         f32x4 acc[NT][2];
 #define R32_BIAS(k) const f32x4 ba = *(const f32x4 *)(sbias + 32 * (k) + 4 * g), bb = *(const f32x4 *)(sbias + 32 * (k) + 16 + 4 * g)
-        __syncthreads();
+        lds_barrier();
         r32_conv<NT, CIN>(img, frs, 0, CONV_BYTES, PW, abase, acc, wq);
-        __syncthreads();
+        lds_barrier();
         {
             R32_BIAS(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
         }
-        __syncthreads();
+        lds_barrier();
         r32_conv<NT, CIN>(img, frs, CONV_BYTES, 2 * CONV_BYTES, PW, abase, acc, wq);
-        __syncthreads();
+        lds_barrier();
         {
             R32_BIAS(1);
 #pragma unroll
@@ -2836,23 +2859,23 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
                 *(f32x4 *)(img + pdst[t][0]) = rs_relu(xs[t][0]); *(f32x4 *)(img + pdst[t][1]) = rs_relu(xs[t][1]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         r32_conv<NT, CIN>(img, frs, 2 * CONV_BYTES, 3 * CONV_BYTES, PW, abase, acc, wq);
-        __syncthreads();
+        lds_barrier();
         {
             R32_BIAS(2);
 #pragma unroll
             for (int t = 0; t < NT; ++t) { *(f32x4 *)(img + pdst[t][0]) = rs_relu(acc[t][0] + ba); *(f32x4 *)(img + pdst[t][1]) = rs_relu(acc[t][1] + bb); }
         }
-        __syncthreads();
+        lds_barrier();
         r32_conv<NT, CIN>(img, frs, 3 * CONV_BYTES, 0, PW, abase, acc, wq);
         {
             R32_BIAS(3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t][0] = (acc[t][0] + ba) + xs[t][0]; acc[t][1] = (acc[t][1] + bb) + xs[t][1];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, (tile0 + t) * 2048, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, (tile0 + t) * 2048 + 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][0]), ors, rowoff, (tile0 + t) * 2048, RS_STREAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t][1]), ors, rowoff, (tile0 + t) * 2048 + 64, RS_STREAM_AUX);
             }
         }
 #undef R32_BIAS
@@ -2860,11 +2883,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * CIN), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, (tile0 + t) * 2048, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, (tile0 + t) * 2048 + 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][0])), rrs, rowoff, (tile0 + t) * 2048, RS_STREAM_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t][1])), rrs, rowoff, (tile0 + t) * 2048 + 64, RS_STREAM_AUX);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -2904,7 +2927,7 @@ __global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__res
     wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
     wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
     const int cq = threadIdx.x & 7;
-    __syncthreads();
+    lds_barrier();
     const long long stride_leaves = (long long)gridDim.x * IMGW;
     for (long long leaf0 = (long long)blockIdx.x * IMGW; leaf0 < B; leaf0 += stride_leaves) {
         const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW);
@@ -2912,18 +2935,18 @@ __global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__res
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = rs_load_b(xrs, rowoff, (tile0 + t) * 16 * CIN * 4 + 64 * q);
+            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = rs_load_x(xrs, rowoff, (tile0 + t) * 16 * CIN * 4 + 64 * q);
         f32x4 acc[NT][2];
-        __syncthreads();
+        lds_barrier();
         r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (m_row[t] < 16 * ((MP + 15) / 16)) {  // rows past the last (partly filled) tile would land beyond the staging area
                 *(f32x4 *)(img + m_row[t] * 36 + 4 * g) = acc[t][0] + ba;
                 *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
             }
-        __syncthreads();
+        lds_barrier();
         float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
         for (int pq = threadIdx.x >> 3; pq < nimg * PP; pq += 8 * WAVES) {
             const int im = pq / PP, pp = pq - im * PP, pr = pp / Wp, px = pp - pr * Wp;
@@ -2939,11 +2962,11 @@ __global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__res
             m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)), fmaxf(fmaxf(v4.w, v5.w), fmaxf(fmaxf(v6.w, v7.w), v8.w)));
             o4[pq * 8 + cq] = m;
         }
-        __syncthreads();
+        lds_barrier();
         if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
             float4 *z4 = (float4 *)img;
             for (int i = threadIdx.x; i < wg_floats / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -3802,16 +3825,16 @@ extern "C" int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out,
     return RP_OK;
 }
 
-static int launch_commit(rp_ctx *ctx, int rows, const float *pi_dev, const float *v_dev, bool logits) {
+static int launch_commit(rp_ctx *ctx, const float *pi_dev, const float *v_dev, bool logits) {
     const DP &d = ctx->d;
-    const dim3 grid(grid_for(rows)), block(64 * WAVES_PER_BLOCK);
-    const size_t lds = logits ? (size_t)WAVES_PER_BLOCK * d.A * sizeof(float) : 0;
+    const dim3 grid(grid_for(d.G)), block(64 * WAVES_PER_BLOCK);  // one wave per slot; waiting slots find their evaluator row in game_row
+    const size_t lds = (size_t)WAVES_PER_BLOCK * std::min(d.A, TERM_CHUNK) * sizeof(double) + (logits ? (size_t)WAVES_PER_BLOCK * d.A * sizeof(float) : 0);
     if (logits) {
         if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
         else hipLaunchKernelGGL((k_commit<u32, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
     } else {
-        if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, false>), grid, block, 0, ctx->stream, d, pi_dev, v_dev);
-        else hipLaunchKernelGGL((k_commit<u32, false>), grid, block, 0, ctx->stream, d, pi_dev, v_dev);
+        if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, false>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
+        else hipLaunchKernelGGL((k_commit<u32, false>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
     }
     hipError_t le_ = hipGetLastError();
     if (le_ != hipSuccess) return fail(ctx, RP_ERR_DEVICE, "launch of k_commit failed: %s", hipGetErrorString(le_));
@@ -3820,14 +3843,14 @@ static int launch_commit(rp_ctx *ctx, int rows, const float *pi_dev, const float
 
 extern "C" int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev) {
     if (!ctx || !pi_dev || !v_dev) return fail(ctx, RP_ERR_ARG, "rp_commit_eval: bad argument");
-    return launch_commit(ctx, ctx->d.G, pi_dev, v_dev, false);
+    return launch_commit(ctx, pi_dev, v_dev, false);
 }
 
 extern "C" int rp_commit_eval_logits(rp_ctx *ctx, const float *logits_dev, const float *v_dev) {
     if (!ctx || !logits_dev || !v_dev) return fail(ctx, RP_ERR_ARG, "rp_commit_eval_logits: bad argument");
     if ((size_t)WAVES_PER_BLOCK * ctx->d.A * sizeof(float) > 24 * 1024)
         return fail(ctx, RP_ERR_ARG, "rp_commit_eval_logits: %d actions do not fit the kernel's LDS row buffers (at most 1536): take the softmax first and call rp_commit_eval", ctx->d.A);
-    return launch_commit(ctx, ctx->d.G, logits_dev, v_dev, true);
+    return launch_commit(ctx, logits_dev, v_dev, true);
 }
 
 extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const float *v_host, int32_t n_rows) {
@@ -3842,7 +3865,7 @@ extern "C" int rp_commit_eval_host(rp_ctx *ctx, const float *pi_host, const floa
     Scratch s(ctx);
     float *dpi = s.up(pi_host, (size_t)n * d.A); NEED(dpi);
     float *dv = s.up(v_host, (size_t)n); NEED(dv);
-    { const int rc = launch_commit(ctx, n, dpi, dv, false); if (rc != RP_OK) return rc; }
+    { const int rc = launch_commit(ctx, dpi, dv, false); if (rc != RP_OK) return rc; }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_device_error(ctx);
 }
