@@ -301,15 +301,17 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
     evaluator, commit) from the event-timed waves; kernel_ms: {kernel label: mean ms per launch} from HIP events."""
     episodes = tot["episodes"]
     K, A = key_bytes(W, H, N), W * N
-    # algorithmic bytes of the tree walk with THIS layout (DESIGN.md section 4).  Per selected node: 32 B header, 4 B prior per
-    # unvisited legal move, 22 B per visited entry (idx, N, Q, P), 6 B (child, action); 26 B per visited entry created;
-    # per backed-up edge 32 B (Q, N, Ns read + write); per expansion: key write + compare 2K, one 512 B probe window,
+    # algorithmic bytes of the tree walk with THIS layout (DESIGN.md section 4).  Per selected node: 32 B header, 6 B best unvisited
+    # candidate, 22 B per visited entry (idx, N, Q, P), 6 B (child, action); 26 B per visited entry created (+ the rescan below);
+    # per backed-up edge 32 B (Q, N, Ns read + write); per expansion: key write + compare 2K, one 128 B probe bucket (16 slots),
     # 32 B header write, 2 B action write per legal move (k_search) and, in k_commit, the 64 B header read-modify-write,
     # the evaluator's 4A + 4 B output, 2 B action read + 4 B prior write per legal move.
-    sel_bytes = 38.0 * tot["path_edges"] + 4.0 * (tot["sum_valid_select"] - tot["sum_visited_select"]) + 22.0 * tot["sum_visited_select"] \
-        + 26.0 * tot["visited_new"]
+    # (round 3) the unvisited moves of a node are represented by ONE cached candidate (6 B: its pi and action); the prior run is scanned
+    # (4 B per legal move) only when that candidate is visited for the first time, i.e. once per new visited entry
+    mean_valid_sel = tot["sum_valid_select"] / max(tot["path_edges"], 1)
+    sel_bytes = 44.0 * tot["path_edges"] + 22.0 * tot["sum_visited_select"] + (26.0 + 4.0 * mean_valid_sel) * tot["visited_new"]
     bak_bytes = 32.0 * tot["path_edges"]
-    exp_bytes = tot["expansions"] * (2 * K + 512 + 32 + 64 + 4 * A + 4) + 8.0 * tot["sum_valid_leaf"]
+    exp_bytes = tot["expansions"] * (2 * K + 128 + 32 + 64 + 4 * A + 4) + 8.0 * tot["sum_valid_leaf"]
     tree_bytes = sel_bytes + bak_bytes + exp_bytes
     tree_ms = per_wave[0] + per_wave[3]
     launches = max(tot["waves"], 1) * groups  # one k_search / evaluator / k_commit launch per group and wave
@@ -413,7 +415,9 @@ def build_output(cfg_name, W, H, N, sims, flops_leaf, games, pool, world, steps,
 # --coach-iter: one CoachBPP iteration at the configuration's scale (BASELINE configs[3]: data-parallel self-play, RCCL all-gather of
 # the replay, all-reduce of the gradients)
 # ---------------------------------------------------------------------------------------------------------------------
-def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start):
+def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start, cfg_name=None):
+    """Plays and trains ONE CoachBPP iteration; returns the JSON line (rank 0) or None (other ranks)."""
+    cfg_name = cfg_name or a.config
     import torch
     import torch.distributed as dist
     from resource_packing_self_play_amd import distributed as rdist
@@ -452,15 +456,16 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
     ar_mean = allreduce([float(np.mean(ar_ms)) if ar_ms else 0.0], dist.ReduceOp.MAX)[0]
     c = sp.counters()
     exp_tot, sim_tot = allreduce([float(c["expansions"]), float(c["simulations"])], dist.ReduceOp.SUM)
+    sp.close()
     if rank != 0:
-        return
+        return None
     steps = int(tm.get("train_steps", 0))
     grad_bytes = 4 * sum(p.numel() for p in nnet.nnet.parameters())
     out = {"metric": "self-play episodes/sec of one CoachBPP iteration (with the iteration's replay exchange and training alongside)",
            "value": n_eps / play_s, "unit": "episodes/s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": wall_max * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64 PUCT / f32 Q + CNN, u32 bit-board", "data": "synthetic",
            "config": {"workload": "%s: one CoachBPP iteration, %dx%d bin, %d items, %d MCTS sims/move, numEps = %d (%d concurrent games per GPU x %d ranks), "
-                                  "replay all-gather + %d optimiser steps of batch 64 with gradient all-reduce" % (a.config, W, H, N, sims, n_eps, games, world, steps),
+                                  "replay all-gather + %d optimiser steps of batch 64 with gradient all-reduce" % (cfg_name, W, H, N, sims, n_eps, games, world, steps),
                       "parallelism": "dp%d (episodes sharded; all-gather of the packed replay, all-reduce of the gradients)" % world},
            "requested": requested, "ranks_joined": joined, "backend": dist.get_backend() if dist.is_initialized() else None,
            "coach": {"numEps": n_eps, "selfplay_s": play_s, "expansions_per_s": exp_tot / play_s, "simulations_per_s": sim_tot / play_s,
@@ -471,8 +476,8 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
                      "maxlenOfQueue": 200000, "train_steps": steps, "train_s": train_s, "train_steps_per_s": steps / train_s if train_s > 0 else None,
                      "grad_allreduce_bytes": grad_bytes + 8, "grad_allreduce_ms_per_step": ar_mean if ar_ms else None, "grad_allreduce_calls": len(ar_ms),
                      "iteration_wall_s": wall_max, "mean_score": float(np.mean(coach.iteration_scores[-1]))},
-           "wall_s_since_start": time.time() - t_start, "device_bytes": sp.device_bytes}
-    print(json.dumps(out), flush=True)
+           "wall_s_since_start": time.time() - t_start}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -509,6 +514,10 @@ def parse_args(argv=None):
                     "one pool and report expansions/s and simulations/s of that window (no episodes/s: no episode ends inside it)")
     ap.add_argument("--coach-iter", action="store_true", help="time ONE CoachBPP iteration (CoachBPP.py:123-176) instead of self-play pools: self-play of numEps = "
                     "games x ranks episodes, the replay all-gather, training steps with the gradient all-reduce; default configuration c4 (BASELINE configs[3])")
+    ap.add_argument("--no-coach-block", action="store_true", help="with several ranks the run ends with one short CoachBPP iteration (c4's 100 sims/move, "
+                    "<= 8 192 games per GPU) so that the line carries the two exchanges of BASELINE configs[3] -- replay all-gather and gradient all-reduce -- "
+                    "timed over RCCL; this switches it off")
+    ap.add_argument("--coach-block-s", type=float, default=100.0, help="hard deadline of that block: past it the process exits 0 and the line printed before stands")
     ap.add_argument("--train-steps", type=int, default=200, help="--coach-iter: optimiser steps that are timed (the reference's epochs x len / batch would be ~30 000)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (ranks, process group, collectives, JSON line) without the GPU work")
     ap.add_argument("--cpu-worker", default=None)
@@ -527,6 +536,8 @@ def main(argv=None):
         sys.exit(spawn_ranks(a.gpus, argv))
 
     t_start = float(os.environ.get("RP_BENCH_T0", T_PROCESS_START))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not a.no_coach_block and a.budget == DEFAULT_BUDGET_S:
+        a.budget = DEFAULT_BUDGET_S - 60.0  # room for the coach block behind the pools
     W, H, N, sims, flops_leaf, games_default, edge_factor_default = CONFIGS[a.config]
     a.edge_factor = a.edge_factor or edge_factor_default
     sims = a.sims or sims
@@ -581,7 +592,9 @@ def main(argv=None):
     torch.manual_seed(0)
     nnet = NNetWrapper(game, args)
     if a.coach_iter:
-        coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start)
+        line = coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, dev, allreduce, requested, t_start)
+        if line is not None:
+            print(json.dumps(line), flush=True)
         if dist.is_initialized():
             dist.destroy_process_group()
         return
@@ -759,6 +772,28 @@ def main(argv=None):
             print(json.dumps(out), flush=True)
         if not go:
             break
+    # ---- several ranks: one short CoachBPP iteration for the configuration's two exchanges (BASELINE configs[3]) ----
+    # Supplementary: the line above is final and already printed.  The block runs under a hard deadline -- a rank that fails or hangs in
+    # a collective makes every rank leave with exit code 0 through its own watchdog, and the printed line stands.
+    if rdist.collectives_on() and not a.no_coach_block and not a.profile_waves:
+        import threading
+        threading.Timer(a.coach_block_s, lambda: os._exit(0)).start()
+        try:
+            last_out = out if rank == 0 else None
+            sp.close()  # engines, captured graphs and evaluator buffers of the pools: 152 GB back before the block allocates
+            torch.cuda.empty_cache()
+            a.train_steps = min(a.train_steps, 100)
+            torch.manual_seed(0)
+            nnet2 = NNetWrapper(game, Args(numMCTSSims=100, cpuct=1, alpha=0.75, cuda=True, num_items=N, num_bins=1, epochs=1, batch_size=64))
+            line = coach_iteration(a, W, H, N, 100, min(games, 8192), game, nnet2, rank, world, joined, dev, allreduce, requested, t_start, cfg_name="c4")
+            if rank == 0 and line is not None and last_out is not None:
+                last_out["coach"] = dict(line["coach"], workload=line["config"]["workload"], backend=line["backend"])
+                last_out["wall_s_since_start"] = time.time() - t_start
+                print(json.dumps(last_out), flush=True)
+        except BaseException as exc:  # the pools' line stands
+            print("coach block failed on rank %d: %r" % (rank, exc), file=sys.stderr, flush=True)
+            os._exit(0)
+        os._exit(0)  # skip process-group teardown: nothing may turn a finished run into a hang
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -403,6 +403,9 @@ class Engine:
         torch.cuda.synchronize(device)  # the tensors come from the caller's stream, the copies run on the context's
         self._ck(self.L.rp_examples_packed(self.h, E, S, *[C.c_void_p(t[k].data_ptr()) for k in
                                                            ("key", "wh", "value", "sp_off", "sp_n", "sp_act", "sp_cnt", "episode", "move")]))
+        # the copies run on the CONTEXT's stream; the caller's next torch operation on these tensors runs on torch's current stream, which
+        # does not wait for it (torch's streams are non-blocking): hand the tensors over only once the copies have finished
+        self.check()
         return t
 
     def expand_examples(self, index, key, wh, value, sp_off, sp_n, sp_act, sp_cnt, planes, pi, value_out):

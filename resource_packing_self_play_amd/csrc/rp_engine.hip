@@ -60,7 +60,8 @@ struct NodeHdr {    // 32 bytes = two dwordx4 loads per visited node
     int8_t term;    // Es[s]: 0 not ended, +1 / -1 ranked outcome (:78-83)
     u8 flags;       // bit 0 expanded (s in Ps), bit 1 uniform-fallback prior (:93-100), bits 2-3 kind of term
     u8 depth;       // items already placed in this state = level of the node in the game
-    u8 pad[3];
+    u8 pad;
+    u16 best_k;     // the best UNVISITED legal move (index into the prior run): largest pi, lowest index among equals; 0xFFFF = none left
     double norm;    // np.sum(Ps[s]) that renormalises the masked prior (:90-92), or the fallback's sum (:100)
 };
 #define HF_EXPANDED 1u
@@ -189,6 +190,7 @@ __device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfir
 // from a node header or a slot's state is per-lane VALU work behind exec masks.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uni_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ u64 uni(u64 v) { return ((u64)uni((u32)(v >> 32)) << 32) | (u64)uni((u32)v); }
 __device__ __forceinline__ void wave_sync() {
     // LDS / global accesses of one wave are issued in order; this only stops the compiler from moving
@@ -525,9 +527,10 @@ template <typename row_t, bool BIG = true> struct Tree {
                    // kernel that already spills scalar registers) -- count() adds, add_counters() flushes
     u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
     u64 *vm;       // this wave's LDS scratch for gen_valid_moves ([VM_WORDS]), with `stage`
+    u32 *vmask;    // this wave's LDS bit mask over a node's legal moves ([MAX_MASK_WORDS]; kernels that can add visited edges), else null
     int have_sizes = 0, w_lo = 0, h_lo = 0, w_hi = 0, h_hi = 0;  // the slot's item sizes in lanes (load_sizes), constant over an episode
 
-    __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr, u64 *vm_ = nullptr) : p(p_), g(g_), stage(stage_), vm(vm_) {
+    __device__ Tree(const DP &p_, int g_, u16 *stage_ = nullptr, u64 *vm_ = nullptr, u32 *vmask_ = nullptr) : p(p_), g(g_), stage(stage_), vm(vm_), vmask(vmask_) {
         hdr = slot_region(p, p.hdr, g);
         key = slot_region(p, p.key, g);
         pAct = slot_region(p, p.pAct, g); pPi = slot_region(p, p.pPi, g);
@@ -691,7 +694,7 @@ template <typename row_t, bool BIG = true> struct Tree {
         }
         NodeHdr hd;
         hd.ns = 0; hd.prior_off = off; hd.vis_off = 0; hd.n_valid = (u16)nv; hd.vis_n = 0; hd.vis_cap = 0; hd.term = 0;
-        hd.flags = (u8)(RP_KIND_WEAK << 2); hd.depth = (u8)level; hd.pad[0] = hd.pad[1] = hd.pad[2] = 0; hd.norm = 0.0;
+        hd.flags = (u8)(RP_KIND_WEAK << 2); hd.depth = (u8)level; hd.pad = 0; hd.best_k = 0xFFFFu; hd.norm = 0.0;
         if (nv == 0) {  // no legal move: game over (BinPackingGame.py:112-114)
             double r;
             int e = ranked_reward<row_t>(myrow, p.H, p.W, p.total_area[g], p.max_h[g], p.has_buf[g] != 0, p.bl[g], &r);
@@ -761,66 +764,83 @@ template <typename row_t, bool BIG = true> struct Tree {
         wave_sync();
         return true;
     }
+    // The best UNVISITED legal move of a node.  Among a node's unvisited moves the PUCT score is u = (cpuct * P) * sqrt(Ns + EPS) with
+    // P = float64(pi) / norm: for cpuct > 0 and probabilities pi >= 0 it is strictly increasing in the float32 pi (two different float32
+    // values are >= 2^-24 apart relatively, the three float64 roundings move a value by 2^-53 each), and the reference's strict '>' in
+    // ascending action order keeps the lowest index among equal scores.  So "the unvisited move that wins the argmax" is the one with
+    // the largest pi, lowest index among equals -- whatever Ns is.  It is kept in the header (best_k) and changes only when that move is
+    // visited for the first time: a selection then costs the node's VISITED records plus one candidate, not a pass over all its legal
+    // moves (54 at 20x20 / 32, 340-460 at 50x50 / 128 where a simulation walks ~26 nodes).  `taken`: a move to treat as visited already.
+    __device__ u32 rescan_best(const NodeHdr &hd, u32 taken) {
+        const int lane = lane_id();
+        if (vmask == nullptr) { if (lane == 0) set_error(p, ERR_PATH); return 0xFFFFu; }
+        const u32 words = ((u32)hd.n_valid + 31u) >> 5;
+        for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
+        wave_sync();
+        for (u32 j = lane; j < hd.vis_n; j += 64) { const u32 k = vis[hd.vis_off + j].idx; atomicOr(&vmask[k >> 5], 1u << (k & 31)); }
+        if (lane == 0 && taken < hd.n_valid) atomicOr(&vmask[taken >> 5], 1u << (taken & 31));
+        wave_sync();
+        float bp = -INFINITY;
+        u32 bk = 0xFFFFu;
+        for (u32 k = lane; k < hd.n_valid; k += 64) {
+            if ((vmask[k >> 5] >> (k & 31)) & 1u) continue;
+            const float x = pPi[hd.prior_off + k];
+            if (x > bp || bk == 0xFFFFu) { bp = x; bk = k; }  // k ascends within a lane: '>' keeps the lowest index among equals
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float op = __shfl_xor(bp, o);
+            const u32 ok = __shfl_xor(bk, o);
+            if (ok != 0xFFFFu && (bk == 0xFFFFu || op > bp || (op == bp && ok < bk))) { bp = op; bk = ok; }
+        }
+        wave_sync();  // the mask is reused
+        return uni(bk);
+    }
     // appends the visited entry of legal move k (Nsa = 0 until the backup reaches it); returns its index or NONE32.  pi = the move's
-    // float32 prior (pPi[hd.prior_off + k], which the caller has in a register already)
+    // float32 prior (pPi[hd.prior_off + k], which the caller has in a register already).  Keeps the header's best unvisited move.
     __device__ u32 append_visited(u32 node, NodeHdr &hd, u32 k, float pi) {
         if (hd.vis_n == hd.vis_cap && !grow_visited(node, hd)) return NONE32;
         const u32 e = hd.vis_off + hd.vis_n;
+        u32 nb = hd.best_k;
+        if (hd.n_valid > 64u && k == hd.best_k) nb = rescan_best(hd, k);  // hd.vis_n: the records before this one; k itself counts as visited
         if (lane_id() == 0) {
             VisEntry v;
             v.q = 0.0; v.p = prior_of(pi, hd.norm, (hd.flags & HF_FALLBACK) != 0); v.n = 0u; v.child = NONE32; v.idx = k; v.pad = 0u;
             vis[e] = v;
             hdr[node].vis_n = (u16)(hd.vis_n + 1);
+            if (nb != hd.best_k) hdr[node].best_k = (u16)nb;
         }
         hd.vis_n++;
+        hd.best_k = (u16)nb;
         return e;
     }
-    // PUCT argmax (MCTS_bpp.py:106-121), float64, strict '>' in ascending action order == maximum with the lowest legal-
-    // move index.  Visited edges come from the node's block (Q + cpuct*P*sqrt(Ns)/(1+Nsa)), all others from the prior run
-    // (cpuct*P*sqrt(Ns+EPS)); an LDS bit mask tells the two apart.  Returns the visited-entry index of the chosen edge
-    // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.  act_out: the edge's action when it
-    // was chosen among the unvisited moves (the only edges whose child still has to be resolved), else -1.
-    // Memory round trips: the prior run's first 64 (action, pi) pairs are requested BEFORE the visited pass, and the winner's pi
-    // and action ride through the argmax shuffles -- append_visited and resolve_child then need no dependent re-read.
-    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 *vmask, u32 &k_out, u32 &child_out, int &act_out) {
+    // The same selection for a node whose legal moves fit ONE pass of the wave (n_valid <= 64: nearly every node at 20x20 / 32): every
+    // move is scored -- the prior run's (pi, action) pairs are requested together with the visited records, one round trip, one argmax --
+    // which is cheaper there than keeping best_k current (a rescan is a dependent round trip per first visit).
+    __device__ u32 select_edge_small(u32 node, NodeHdr &hd, u32 &k_out, u32 &child_out, int &act_out) {
         const int lane = lane_id();
-        const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
-        const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
+        const double s_vis = sqrt((double)hd.ns), s_new = sqrt((double)hd.ns + 1e-8);
         double best_u = -INFINITY;
         u32 best_k = NONE32, best_e = NONE32, best_c = NONE32;
-        float best_pi = 0.f;
-        int best_a = -1;
         float pi0 = 0.f;
         int act0 = 0;
-        if ((u32)lane < hd.n_valid) { pi0 = pPi[hd.prior_off + lane]; act0 = pAct[hd.prior_off + lane]; }
-        const bool any_visited = hd.vis_n != 0;
-        if (any_visited) {
-            const u32 words = ((u32)hd.n_valid + 31u) >> 5;
-            for (u32 w = lane; w < words; w += 64) vmask[w] = 0u;
-            wave_sync();
-            for (u32 j = lane; j < hd.vis_n; j += 64) {
-                const u32 e = hd.vis_off + j;
-                const VisEntry v = vis[e];  // two 16-byte loads; the child link rides along: no extra round trip after the argmax
-                const u32 k = v.idx;
-                atomicOr(&vmask[k >> 5], 1u << (k & 31));
-                u32 nn = v.n & NSA_MASK, ch = v.child;
-                double cp = p.cpuct * v.p;
-                double u = nn ? v.q + cp * s_vis / (double)(1u + nn) : cp * s_new;
-                if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; best_a = -1; }
-            }
-            wave_sync();
+        const bool mine = (u32)lane < hd.n_valid;
+        if (mine) { pi0 = pPi[hd.prior_off + lane]; act0 = pAct[hd.prior_off + lane]; }
+        u64 bit = 0ull;  // 1 << (legal move of this lane's visited record): OR-ed over the wave it marks the visited moves, no LDS mask
+        if ((u32)lane < hd.vis_n) {  // vis_n <= n_valid <= 64: one record per lane
+            const u32 e = hd.vis_off + lane;
+            const VisEntry v = vis[e];
+            const u32 k = v.idx, nn = v.n & NSA_MASK;
+            const double cp = p.cpuct * v.p;
+            best_u = nn ? v.q + cp * s_vis / (double)(1u + nn) : cp * s_new;
+            best_k = k; best_e = e; best_c = v.child;
+            bit = 1ull << (k & 63u);
         }
-        const bool fb = (hd.flags & HF_FALLBACK) != 0;
-        for (u32 k = lane; k < hd.n_valid; k += 64) {
-            if (any_visited && ((vmask[k >> 5] >> (k & 31)) & 1u)) continue;
-            const float pik = k < 64u ? pi0 : pPi[hd.prior_off + k];
-            double u = (p.cpuct * prior_of(pik, hd.norm, fb)) * s_new;
-            if (u > best_u || (u == best_u && k < best_k)) {
-                best_u = u; best_k = k; best_e = NONE32; best_c = NONE32; best_pi = pik;
-                best_a = k < 64u ? act0 : (int)pAct[hd.prior_off + k];
-            }
+        const u64 visited = hd.vis_n ? RowOps<u64>::at(wave_scan_or(bit), 63) : 0ull;
+        if (mine && !((visited >> lane) & 1ull)) {  // this lane's own legal move is unvisited: cpuct * P * sqrt(Ns + EPS)
+            const double u = (p.cpuct * prior_of(pi0, hd.norm, (hd.flags & HF_FALLBACK) != 0)) * s_new;
+            if (u > best_u || (u == best_u && (u32)lane < best_k)) { best_u = u; best_k = (u32)lane; best_e = NONE32; best_c = NONE32; }
         }
-        // wave argmax on (u, lowest k) only; the winner's payload (entry, child, pi, action) is then read from its lane
         double win_u = best_u;
         u32 win_k = best_k;
 #pragma unroll
@@ -829,20 +849,73 @@ template <typename row_t, bool BIG = true> struct Tree {
             const u32 ok = __shfl_xor(win_k, o);
             if (ou > win_u || (ou == win_u && ok < win_k)) { win_u = ou; win_k = ok; }
         }
+        k_out = win_k;
+        act_out = -1;
+        child_out = NONE32;
+        if (win_k == NONE32) return NONE32;
+        const int wl = __ffsll((long long)__ballot(best_k == win_k)) - 1;  // legal-move indices are unique among the lanes' candidates
+        best_e = (u32)__builtin_amdgcn_readlane((int)best_e, wl);
+        child_out = (u32)__builtin_amdgcn_readlane((int)best_c, wl);
+        if (best_e == NONE32) {  // an unvisited move won: its (pi, action) sit in lane win_k
+            const float pw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pi0), (int)win_k));
+            act_out = __builtin_amdgcn_readlane(act0, (int)win_k);
+            best_e = append_visited(node, hd, win_k, pw);
+        }
+        return best_e;
+    }
+    // PUCT argmax (MCTS_bpp.py:106-121), float64, strict '>' in ascending action order == maximum with the lowest legal-
+    // move index.  Visited edges come from the node's records (Q + cpuct*P*sqrt(Ns)/(1+Nsa), or cpuct*P*sqrt(Ns+EPS) while Nsa = 0), the
+    // unvisited moves are represented by the header's best_k (see rescan_best).  Returns the visited-entry index of the chosen edge
+    // (appending the entry on a first visit) and its legal-move index in k_out, or NONE32.  act_out: the edge's action when it
+    // was chosen among the unvisited moves (the only edges whose child still has to be resolved), else -1.
+    // Memory round trips: the candidate's (pi, action) are requested with the visited records.
+    __device__ u32 select_edge(u32 node, NodeHdr &hd, u32 &k_out, u32 &child_out, int &act_out) {
+        if (hd.n_valid <= 64u) return select_edge_small(node, hd, k_out, child_out, act_out);
+        const int lane = lane_id();
+        const double s_vis = sqrt((double)hd.ns);          // math.sqrt(self.Ns[s])
+        const double s_new = sqrt((double)hd.ns + 1e-8);   // math.sqrt(self.Ns[s] + EPS)
+        double best_u = -INFINITY;
+        u32 best_k = NONE32, best_e = NONE32, best_c = NONE32;
+        const bool have_new = hd.best_k != 0xFFFFu;
+        float pik = 0.f;
+        int actk = 0;
+        if (have_new) { pik = pPi[hd.prior_off + hd.best_k]; actk = pAct[hd.prior_off + hd.best_k]; }  // wave-uniform addresses
+        for (u32 j = lane; j < hd.vis_n; j += 64) {
+            const u32 e = hd.vis_off + j;
+            const VisEntry v = vis[e];  // two 16-byte loads; the child link rides along: no extra round trip after the argmax
+            const u32 k = v.idx;
+            u32 nn = v.n & NSA_MASK, ch = v.child;
+            double cp = p.cpuct * v.p;
+            double u = nn ? v.q + cp * s_vis / (double)(1u + nn) : cp * s_new;
+            if (u > best_u || (u == best_u && k < best_k)) { best_u = u; best_k = k; best_e = e; best_c = ch; }
+        }
+        // wave argmax on (u, lowest k) only; the winner's payload (entry, child) is then read from its lane
+        double win_u = best_u;
+        u32 win_k = best_k;
+        if (hd.vis_n != 0) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double ou = __shfl_xor(win_u, o);
+                const u32 ok = __shfl_xor(win_k, o);
+                if (ou > win_u || (ou == win_u && ok < win_k)) { win_u = ou; win_k = ok; }
+            }
+        }
         if (win_k != NONE32) {  // uniform; legal-move indices are unique across lanes, so exactly one lane holds the winner
             const int wl = __ffsll((long long)__ballot(best_k == win_k)) - 1;
             best_e = (u32)__builtin_amdgcn_readlane((int)best_e, wl);
             best_c = (u32)__builtin_amdgcn_readlane((int)best_c, wl);
-            best_pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best_pi), wl));
-            best_a = __builtin_amdgcn_readlane(best_a, wl);
         }
-        best_k = win_k;
-        if (any_visited) wave_sync();  // the mask is reused by the next selection
-        k_out = best_k;
+        act_out = -1;
+        if (have_new) {  // the unvisited candidate against the visited winner, same rule: larger u, lower index among equals
+            const double un = (p.cpuct * prior_of(uni_f(pik), hd.norm, (hd.flags & HF_FALLBACK) != 0)) * s_new;
+            if (win_k == NONE32 || un > win_u || (un == win_u && (u32)hd.best_k < win_k)) {
+                win_k = hd.best_k; best_e = NONE32; best_c = NONE32; act_out = uni(actk);
+            }
+        }
+        k_out = win_k;
         child_out = best_c;
-        act_out = best_a;
-        if (best_k == NONE32) return NONE32;
-        if (best_e == NONE32) best_e = append_visited(node, hd, best_k, best_pi);
+        if (win_k == NONE32) return NONE32;
+        if (best_e == NONE32) best_e = append_visited(node, hd, win_k, uni_f(pik));
         return best_e;
     }
     // visited entry of legal move k, or NONE32
@@ -1059,7 +1132,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
     u32 root = p.root[g];
     int sims_done = p.sims_done[g];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t, BIG> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
+    Tree<row_t, BIG> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()], vmask);
     t.load_sizes();
     phase = uni(phase); root = uni(root); sims_done = uni(sims_done); t.n_nodes = uni(t.n_nodes);
     if (phase != RP_PHASE_RUNNING) return;  // MOVE_READY slots were handled by k_moves just before this launch
@@ -1093,7 +1166,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
             u32 ksel, child;
             int act_sel;
             const u32 vis_before = hd.vis_n;
-            u32 e = t.select_edge(node, hd, vmask, ksel, child, act_sel);
+            u32 e = t.select_edge(node, hd, ksel, child, act_sel);
             t.count(CNT_VIS_NEW, hd.vis_n - vis_before);
             if (e == NONE32 || depth >= p.N) { failed = true; break; }
             if (!BIG || depth < 64) { if (lane == depth) { pe0 = e; pn0 = node; } }
@@ -1148,7 +1221,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
     if (p.phase[g] != RP_PHASE_MOVE_READY) return;
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
+    __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()], s_vmask[wave_in_block()]);
     u32 root = p.root[g];
     play_move_impl<row_t>(p, t, g, root, -1);
     wave_sync();
@@ -1210,13 +1284,35 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
 
 // Normaliser of one node's masked prior from the evaluator's pi (MCTS_bpp.py:88-100): np.sum(pi * valids) if that is
 // positive, else the sum of the uniform fallback pi * valids + valids.  The legal moves' float32 pi go to `pi_out`.
+// *best_k_out: the legal move with the largest pi, lowest index among equals (Tree::rescan_best: the first PUCT candidate of the new node).
 __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, float *pi_out, u32 n_valid, u32 *vmask, double *sleaf,
-                               double *sterm, bool *fallback) {
+                               double *sterm, bool *fallback, u32 *best_k_out = nullptr) {
     const int lane = lane_id();
     const int words = (p.A + 31) >> 5;
     for (int w = lane; w < words; w += 64) vmask[w] = 0u;
     wave_sync();
-    for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); pi_out[k] = pi[a]; }
+    float bp = -INFINITY;
+    u32 bk = 0xFFFFu;
+    if (best_k_out == nullptr) {  // uniform: the common case (one-pass nodes) carries no candidate tracking
+        for (u32 k = lane; k < n_valid; k += 64) { int a = act[k]; atomicOr(&vmask[a >> 5], 1u << (a & 31)); pi_out[k] = pi[a]; }
+    } else {
+        for (u32 k = lane; k < n_valid; k += 64) {
+            int a = act[k];
+            atomicOr(&vmask[a >> 5], 1u << (a & 31));
+            const float x = pi[a];
+            pi_out[k] = x;
+            if (x > bp || bk == 0xFFFFu) { bp = x; bk = k; }
+        }
+    }
+    if (best_k_out) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float op = __shfl_xor(bp, o);
+            const u32 ok = __shfl_xor(bk, o);
+            if (ok != 0xFFFFu && (bk == 0xFFFFu || op > bp || (op == bp && ok < bk))) { bp = op; bk = ok; }
+        }
+        *best_k_out = uni(bk);
+    }
     wave_sync();
     double s = numpy_masked_sum(p, pi, vmask, sleaf, sterm, 0);
     *fallback = !(s > 0);                                             // :91
@@ -1283,9 +1379,10 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
         row = sp;
     }
     bool fb;
-    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term_w, &fb);
+    u32 bk = 0xFFFFu;  // kept for nodes whose legal moves take more than one pass of the wave (Tree::select_edge)
+    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term_w, &fb, hd.n_valid > 64u ? &bk : nullptr);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
-        hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm;
+        hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm; hd.best_k = (u16)bk;
         t.hdr[node] = hd;
         p.sims_done[g] += 1; p.phase[g] = RP_PHASE_RUNNING; p.last_v[g] = v; p.last_vkind[g] = RP_KIND_F32;
         u64 *cn = p.slot_cnt + (size_t)g * CNT_N;
@@ -1656,7 +1753,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_advance(DP p, int firs
     if (phase != RP_PHASE_MOVE_READY && phase != RP_PHASE_RUNNING) return;
     extern __shared__ u16 s_stage[];
     __shared__ u64 s_vm[WAVES_PER_BLOCK][VM_WORDS];
-    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()]);
+    __shared__ u32 s_vmask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
+    Tree<row_t> t(p, g, s_stage + (size_t)wave_in_block() * p.A, s_vm[wave_in_block()], s_vmask[wave_in_block()]);
     u32 root = p.root[g];
     play_move_impl<row_t>(p, t, g, root, action[k]);
     t.store_sizes();
@@ -3116,6 +3214,7 @@ extern "C" int rp_create(const rp_config *cfg, rp_ctx **out) {
     if (cfg->W < 1 || cfg->W > 64 || cfg->H < 1 || cfg->H > 64 || cfg->N < 1 || cfg->N > 128)
         return fail(nullptr, RP_ERR_ARG, "limits: 1<=W<=64, 1<=H<=64, 1<=N<=128 (got %d %d %d)", cfg->W, cfg->H, cfg->N);
     if (cfg->games < 1 || cfg->sims < 0) return fail(nullptr, RP_ERR_ARG, "games >= 1 and sims >= 0 required");
+    if (!(cfg->cpuct > 0.0)) return fail(nullptr, RP_ERR_ARG, "cpuct must be positive (got %g): the best unvisited move of a node is kept as the one with the largest prior, which is the PUCT winner among the unvisited moves only for cpuct > 0", cfg->cpuct);
     if ((int64_t)cfg->sims * (cfg->N + 1) >= (int64_t)NSA_MASK) return fail(nullptr, RP_ERR_ARG, "sims too large");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device)

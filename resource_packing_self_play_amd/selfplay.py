@@ -139,6 +139,8 @@ class BatchedSelfPlay:
 
     def close(self):
         for g in self.groups:
+            g.graph = None
+            g.pi = g.v = g.stem = g.stem_relu = g.planes = None
             g.eng.close()
 
     @property
