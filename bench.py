@@ -47,7 +47,8 @@ CONFIGS = {  # name: W, H, N, sims, FLOPs per evaluator forward (SURVEY.md secti
     "c2": (10, 10, 8, 100, 2.18e6, 4096, 24),
     "c3": (20, 20, 32, 400, 10.01e6, 32768, 24),
     "c4": (20, 20, 32, 100, 10.01e6, 32768, 24),
-    "c5": (50, 50, 128, 800, 133.4e6, 1024, 160),  # 175 MB per slot: 1 024 games = 179 GB of the 288 GB
+    "c5": (50, 50, 128, 800, 133.4e6, 768, 224),  # 221 MB per slot: 768 games = 170 GB of the 288 GB (legal-move arena peak of a whole pool:
+    # 102 MB per slot, profiles/r03_b_c5_full_pool_768games.json; 1 024 games x 160 overflowed it 100 k waves in)
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak
@@ -439,6 +440,7 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
     if rdist.collectives_on():  # more than one rank, or a forced one-rank group (RP_DIST_FORCE=1: RCCL smoke run on one GPU)
         rdist.attach(nnet)
         nnet.grad_hook.timing = []
+    nnet.step_timing = []
     coach.drawIteration = lambda: (H, list(range(100, 100 + n_eps)))  # the bench's instances: seeds 100 + global episode index, full-height rectangle
     sp = coach._driver(n_eps)
     sp.prepare()  # evaluator warm-up + graph capture outside the timed iteration
@@ -452,8 +454,12 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
     tm = coach.timings[-1]
     hook = nnet.grad_hook
     ar_ms = [e0.elapsed_time(e1) for e0, e1 in hook.timing] if (hook is not None and hook.timing) else []
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in nnet.step_timing]
+    steady = step_ms[len(step_ms) // 2:]  # the first half carries MIOpen's kernel search for the training shapes
+    step_med = allreduce([float(np.median(steady)) if steady else 0.0], dist.ReduceOp.MAX)[0]
+    ar_steady = ar_ms[len(ar_ms) // 2:]
     play_s, exch_ms, train_s, wall_max = allreduce([tm["selfplay_s"], tm["exchange"]["ms"], tm.get("train_s", 0.0), wall], dist.ReduceOp.MAX)
-    ar_mean = allreduce([float(np.mean(ar_ms)) if ar_ms else 0.0], dist.ReduceOp.MAX)[0]
+    ar_mean = allreduce([float(np.median(ar_steady)) if ar_steady else 0.0], dist.ReduceOp.MAX)[0]
     c = sp.counters()
     exp_tot, sim_tot = allreduce([float(c["expansions"]), float(c["simulations"])], dist.ReduceOp.SUM)
     sp.close()
@@ -473,7 +479,10 @@ def coach_iteration(a, W, H, N, sims, games, game, nnet, rank, world, joined, de
                      "dense_bytes_per_example": 4 * ((N + 1) * H * W + W * N + 1),
                      "allgather_bytes_sent_per_rank": tm["exchange"]["bytes_sent"], "allgather_bytes_received_per_rank": tm["exchange"]["bytes_received"],
                      "allgather_ms": exch_ms, "train_set_examples": tm.get("train_examples"), "train_set_bytes": tm.get("train_set_bytes"),
-                     "maxlenOfQueue": 200000, "train_steps": steps, "train_s": train_s, "train_steps_per_s": steps / train_s if train_s > 0 else None,
+                     "maxlenOfQueue": 200000, "train_steps": steps, "train_s": train_s, "train_steps_per_s_incl_kernel_search": steps / train_s if train_s > 0 else None,
+                     "train_ms_per_step": step_med or None, "train_steps_per_s": 1e3 / step_med if step_med else None,
+                     "train_note": "ms per step: median over the second half of the timed steps (HIP events around one whole step incl. the minibatch expansion and "
+                                   "the gradient all-reduce); the first steps carry MIOpen's kernel search for the training shapes",
                      "grad_allreduce_bytes": grad_bytes + 8, "grad_allreduce_ms_per_step": ar_mean if ar_ms else None, "grad_allreduce_calls": len(ar_ms),
                      "iteration_wall_s": wall_max, "mean_score": float(np.mean(coach.iteration_scores[-1]))},
            "wall_s_since_start": time.time() - t_start}

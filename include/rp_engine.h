@@ -66,7 +66,7 @@ typedef struct rp_config {
     int32_t W, H, N;       /* BinPackingGame(bin_width, bin_height, num_items, n) BinPackingGame.py:15 */
     int32_t games;         /* concurrent game slots G on this GPU */
     int32_t sims;          /* args.numMCTSSims (MCTS_bpp.py:37) */
-    double cpuct;          /* args.cpuct (MCTS_bpp.py:114,117) */
+    double cpuct;          /* args.cpuct (MCTS_bpp.py:114,117); must be > 0 (see rp_commit_eval) */
     double alpha;          /* args.alpha (MCTS_bpp.py:79) */
     int32_t node_cap;      /* per-game node arena; 0 = sims * (N + 1) + 2 */
     int32_t edge_cap;      /* per-game legal-move arena (one 6-byte entry per legal move of every node); 0 = automatic */
@@ -231,7 +231,9 @@ int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out /*[n][H]*/,
 /* Expansion + backup: masks and renormalises pi with the leaf's valid moves (MCTS_bpp.py:88-100,
  * float64, NumPy summation order), stores Vs/Ns (:102-103) and backs v up the path (:130-139).
  * pi_dev [n][W*N] and v_dev [n] are DEVICE float32 (probabilities, i.e. exp(log_softmax), NNet.py:85),
- * row b belonging to the b-th waiting leaf. */
+ * row b belonging to the b-th waiting leaf.  pi must be what NNet.predict returns -- probabilities, pi >= 0: for a node with more
+ * than 64 legal moves the search keeps "the unvisited move with the largest pi (lowest action among equals)" as the one PUCT
+ * candidate of all unvisited moves, which is the reference's argmax over them exactly when cpuct > 0 and pi >= 0. */
 int rp_commit_eval(rp_ctx *ctx, const float *pi_dev, const float *v_dev);
 /* The same from the policy head's raw outputs (logits_fc, BinpackingNNet.py:69,79): the softmax of NNet.predict (NNet.py:81-85:
  * exp(log_softmax(x))) is taken inside the kernel, float32, exp(x - max) / sum -- no separate softmax pass over [n][W*N].

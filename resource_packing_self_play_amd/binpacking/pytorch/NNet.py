@@ -128,7 +128,10 @@ class NNetWrapper(NeuralNet):
             cap = getattr(self.args, "max_train_steps_per_epoch", None)  # measurement aid (bench.py --coach-iter); the reference has no cap
             if cap:
                 steps = min(steps, int(cap))
+            timing = getattr(self, "step_timing", None)  # a list: (start event, end event) per optimiser step (bench.py --coach-iter)
             for _ in range(steps):
+                if timing is not None and device.type == "cuda":
+                    ev0 = torch.cuda.Event(enable_timing=True); ev0.record()
                 ids_all = draw(n, size=B)
                 ids = torch.as_tensor(ids_all[rank::world], device=device)
                 x, t_pi, t_v = fetch(ids)
@@ -142,6 +145,9 @@ class NNetWrapper(NeuralNet):
                 if self.grad_hook is not None:
                     l_pi, l_v = self.grad_hook(self.nnet, (l_pi, l_v))
                 optimizer.step()
+                if timing is not None and device.type == "cuda":
+                    ev1 = torch.cuda.Event(enable_timing=True); ev1.record()
+                    timing.append((ev0, ev1))
                 step_losses.append(torch.stack([l_pi.reshape(()), l_v.reshape(())]))  # read back once per epoch: no host sync per step
                 self.last_train_steps += 1
             if step_losses:
