@@ -1629,9 +1629,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
             // output the rectangle does not reach reads the all-zero row behind the table instead of being skipped -- no exec-mask
             // juggling around the four outputs, and the 16 loads of an item are independent of each other.
             const int r0b = ra == 0 ? 2 : 0, c0b = xa == 0 ? 2 : 0, zrow = p.N * 25;
-            for (int i = 0; i < p.N; ++i) {
-                if (!((i < 64 ? rem0 >> i : rem1 >> (i - 64)) & 1ull)) continue;  // placed item: plane of zeros
-                const int whi = i < 64 ? __builtin_amdgcn_readlane(wh_lo, i) : __builtin_amdgcn_readlane(wh_hi, i - 64);
+            // The items worth a look in this pass: unplaced (a placed item's plane is zero) and tall enough to reach the pass's first image
+            // row -- an item's rectangle is anchored at the origin, so every pass below its height skips it without touching it (at the
+            // 50x50 board 12 of 16 passes lie below nearly every item; testing all 128 items in each cost as much as the adds).
+            const int thr = 2 * (base / p.Wp);
+            const u64 cand[2] = {__ballot((wh_lo >> 8) >= thr) & rem0, p.N > 64 ? (__ballot((wh_hi >> 8) >= thr) & rem1) : 0ull};
+            for (int half = 0; half < 2; ++half)
+            for (u64 m = cand[half]; m; m &= m - 1) {
+                const int il = __ffsll((long long)m) - 1, i = il + 64 * half;
+                const int whi = half ? __builtin_amdgcn_readlane(wh_hi, il) : __builtin_amdgcn_readlane(wh_lo, il);
                 const int iw = whi & 255, ih = whi >> 8;
                 const int dr = ih - ra, dc = iw - xa;  // >= 0: output (ra, xa) has a tap inside the rectangle
                 if (__ballot(live && dr >= 0 && dc >= 0) == 0ull) continue;  // the item's rectangle (+1 border) misses every lane's block
