@@ -8,10 +8,11 @@
 // board.  Every tree of a slot is a structure of arrays in HBM: 32-byte node headers, bit-packed
 // node keys (the state), per-node CONTIGUOUS runs of the legal moves' (action u16, prior f32) -- 6 bytes
 // per legal move, written once at expansion -- and per-node blocks of VISITED edges only
-// (index, P, Q, N, child; grown by doubling), because a search visits ~2 % of the edges it creates.
-// A wave reads a node's priors and visited block as coalesced 64-lane loads.  Transpositions (the reference keys its dicts by the
-// full state, MCTS_bpp.py:20-26,76) go through a per-slot open-addressing table probed 64 slots per wave instruction.  A slot's
-// ten regions lie back to back in ONE slab (DP::slab_stride), and everything that is the same in all lanes of a wave -- the slot
+// (32-byte records: Q, P, N, child, index; grown by doubling), because a search visits ~2 % of the edges it creates.
+// A wave reads a node's priors and visited records as coalesced 64-lane loads; a node with more legal moves than lanes keeps its best
+// unvisited move in the header, so a selection scores the visited records plus that one candidate.  Transpositions (the reference keys
+// its dicts by the full state, MCTS_bpp.py:20-26,76) go through a per-slot open-addressing table probed one aligned 16-slot bucket (one
+// 128-byte line) at a time.  A slot's regions lie back to back in ONE slab (DP::slab_stride), and everything that is the same in all lanes of a wave -- the slot
 // id, region pointers, node headers, counters -- is kept in scalar registers (wave_in_block(), uni()).
 //
 // Numerics: compiled with -ffp-contract=off; the PUCT score is float64, Q follows the NumPy promotion

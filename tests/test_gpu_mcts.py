@@ -58,6 +58,10 @@ CASES = [  # W, H, N, sims, games, kind, rule
     (15, 15, 10, 40, 16, "uniform", "argmax"),
     (33, 12, 9, 30, 8, "hashed", "sample"),  # 64-bit rows
     (50, 50, 128, 10, 3, "peaked", "argmax"),
+    # nodes on both sides of the 64-legal-move boundary (one-pass scoring below it, cached best unvisited move + rescans above it)
+    (16, 16, 14, 60, 10, "peaked", "sample"),
+    (40, 30, 60, 16, 4, "uniform", "argmax"),  # equal priors everywhere: every first visit takes the lowest unvisited action and rescans
+    (24, 24, 40, 40, 6, "sparse", "sample"),   # zeros among the priors and the all-zero fallback on nodes with > 64 legal moves
 ]
 
 
