@@ -348,7 +348,7 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
             if (lane == 0) sink.vm[64 + i] = v;
         }
     }
-    if (sink.mask) wave_sync(); else lds_sync();  // only the dense-mask variant exchanges data through global memory
+    wave_sync();
     // lanes = items: counts, offsets, actions in ascending order
     u64 m_lo = sink.vm[lane], m_hi = big ? sink.vm[64 + lane] : 0ull;
     int inc_lo = __popcll(m_lo), inc_hi = __popcll(m_hi);
@@ -359,7 +359,7 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
     if (sink.mask)
         for (int a = lane; a < p.A; a += 64) sink.mask[a] = 0;
     if (sink.act && nv > sink.cap) return -1;
-    if (sink.mask) wave_sync(); else lds_sync();  // only the dense-mask variant exchanges data through global memory
+    wave_sync();
     int pos = inc_lo - c_lo;
     for (; m_lo; m_lo &= m_lo - 1) {
         const int a = lane * W + (__ffsll((long long)m_lo) - 1);
@@ -374,7 +374,7 @@ __device__ int gen_valid_moves(const DP &p, const u8 *wh, row_t myrow, u64 rem0,
         if (sink.mask) sink.mask[a] = 1;
         ++pos;
     }
-    if (sink.mask) wave_sync(); else lds_sync();  // only the dense-mask variant exchanges data through global memory
+    wave_sync();
     return nv;
 }
 
@@ -524,8 +524,6 @@ template <typename row_t, bool BIG = true> struct Tree {
     const u8 *wh;
     Arena pa, va;  // legal-move runs, visited blocks
     u32 n_nodes;
-    int new_term = 0;   // Es and its kind of the node the latest materialize() created
-    u32 new_kind = 0;
     u32 cnt = 0;   // per-launch event counts: LANE k holds counter k (one VGPR; sixteen wave-uniform counters took sixteen SGPRs of a
                    // kernel that already spills scalar registers) -- count() adds, add_counters() flushes
     u16 *stage;    // this wave's LDS staging run of A actions (kernels that can create nodes), else null
@@ -684,7 +682,7 @@ template <typename row_t, bool BIG = true> struct Tree {
         sink.act = stage; sink.mask = nullptr; sink.cap = p.A; sink.vm = vm;
         sink.have_sizes = have_sizes; sink.w_lo = w_lo; sink.h_lo = h_lo; sink.w_hi = w_hi; sink.h_hi = h_hi;
         const int nv = gen_valid_moves<row_t, BIG>(p, wh, myrow, rem0, rem1, sink);
-        lds_sync();  // the staging run lives in LDS
+        wave_sync();
         u32 room, off = 0;
         if (nv > 0) {
             off = arena_reserve(pa, level, (u32)nv, &room);
@@ -708,7 +706,6 @@ template <typename row_t, bool BIG = true> struct Tree {
             hdr[id] = hd;
             table[insert_slot] = ((u64)(u32)(h >> 32) << 32) | (u64)(id + 1u);
         }
-        new_term = hd.term; new_kind = hdr_term_kind(hd);  // what a load of the new header would return (k_search does not wait for it)
         n_nodes++;
         count(CNT_NODES);
         return id;
@@ -1181,15 +1178,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, SEARCH_WAVES) k_search(D
                 bool was_new;
                 child = t.resolve_child(node, e, act_sel >= 0 ? act_sel : (int)t.pAct[hd.prior_off + ksel], &was_new, key_ahead, kv);
                 if (child == NONE32) { failed = true; break; }
-                if (was_new) {
-                    // The new node's header is known here -- not expanded, or terminal with its ranked value -- so the next level of the
-                    // recursion (:78-87) is decided without loading it back (a dependent round trip behind the stores just issued).
-                    node = child;
-                    if (t.new_term != 0) { v = (double)t.new_term; vkind = t.new_kind; t.count(CNT_TERMINAL); }
-                    else need_eval = true;
-                    break;
-                }
-                t.count(CNT_TRANSPOSE);  // the edge's child link (lane 0's store) is read again after this simulation's closing wave_sync at the earliest
+                if (!was_new) t.count(CNT_TRANSPOSE);
+                wave_sync();
             }
             node = child;
         }
@@ -1260,7 +1250,7 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
         const int lend = (lb + 8 < p.n_leaves ? lb + 8 : p.n_leaves) - 1;
         const int glo = p.leaf_lo[lb], ghi = p.leaf_lo[lend] + p.leaf_n[lend];
         for (int a = glo + lane; a < ghi; a += 64) sterm[a - glo] = prior_term(pi, vmask, a, mode);
-        lds_sync();
+        wave_sync();
         // ... then every (leaf, accumulator) pair runs its sequential chain out of LDS
         int l = lb + (lane >> 3);
         bool act = l < p.n_leaves;
@@ -1283,13 +1273,13 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
             }
         }
         if (act && j == 0) sleaf[l] = res;
-        lds_sync();
+        wave_sync();
     }
     if (lane == 0)
         for (int k = 0; k < p.n_leaves - 1; ++k) sleaf[p.sched_dst[k]] = sleaf[p.sched_dst[k]] + sleaf[p.sched_src[k]];
-    lds_sync();
+    wave_sync();
     double total = sleaf[0];
-    lds_sync();
+    wave_sync();
     return total;
 }
 
@@ -1301,7 +1291,7 @@ __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, flo
     const int lane = lane_id();
     const int words = (p.A + 31) >> 5;
     for (int w = lane; w < words; w += 64) vmask[w] = 0u;
-    lds_sync();
+    wave_sync();
     float bp = -INFINITY;
     u32 bk = 0xFFFFu;
     if (best_k_out == nullptr) {  // uniform: the common case (one-pass nodes) carries no candidate tracking
@@ -1324,7 +1314,7 @@ __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, flo
         }
         *best_k_out = uni(bk);
     }
-    lds_sync();
+    wave_sync();
     double s = numpy_masked_sum(p, pi, vmask, sleaf, sterm, 0);
     *fallback = !(s > 0);                                             // :91
     if (*fallback) s = numpy_masked_sum(p, pi, vmask, sleaf, sterm, 1);  // :93-100  Ps = Ps + valids; Ps /= sum(Ps)
