@@ -2554,19 +2554,30 @@ __global__ void k_pack_conv32(const float *w, float *frag, int Cin) {
     const int co = 16 * mt + (l & 15), ci = (Cin / 4) * (l >> 4) + 4 * h + j;
     frag[i] = w[(co * Cin + ci) * 9 + tap];
 }
-template <int CIN> __device__ __forceinline__ int r32_swz(int p) { return (3 * (p >> 1)) & (CIN / 4 - 1); }
-// One 3x3 convolution CIN -> 32 over NT pixel tiles on the swizzled image.  abase[t]: pixel index (not an offset) of the top-left
-// tap of tile t's pixel of this lane; wq: fragments of half-taps (0, 1) on entry, of the NEXT convolution's (byte offset fnext) on exit.
+// Image geometry of the 32-channel kernels (round 3): pixel stride CIN + 4 floats and ONE pad column shared by neighbouring rows
+// (row pitch W + 1: the right neighbour of a row's last pixel is the left pad of the next row), + one cell behind the bottom pad row for
+// the bottom-right tap of the last pixel.  A tap's operand address is then (lane's base) + (wave-uniform tap offset): ONE VALU add per
+// ds_read_b128.  The XOR swizzle this replaces (quad slot Q ^ swz(pixel), images without padding floats) cost ~7 VALU instructions per
+// read -- 2 286 of k_resstage32<5>'s 5 166 vector instructions -- and vector issue is what the two waves of a SIMD compete for beside
+// the MFMA stream (MI355X_MICROARCH.md, 'Two waves per SIMD'): rs5 0.743 -> 0.78 of peak with the addresses alone.  Stride CIN + 4
+// keeps the sixteen pixels of a tile on different bank quads (36 p mod 64 = 4 (9 p mod 16)).
+#define R32_PAD 4
+__host__ __device__ constexpr int r32_ps(int cin) { return cin + R32_PAD; }
+__host__ __device__ inline int r32_pw(int W) { return W + 1; }
+__host__ __device__ inline int r32_imgp(int H, int W) { return (H + 2) * (W + 1) + 1; }
+// One 3x3 convolution CIN -> 32 over NT pixel tiles on the padded image.  abase[t]: FLOAT offset of this lane's first channel quad
+// (input channels CIN/4 * g ..) of the top-left tap of tile t's pixel of this lane; wq: fragments of half-taps (0, 1) on entry, of the
+// NEXT convolution's (byte offset fnext) on exit.
 template <int NT, int CIN>
 __device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
                                          f32x4 (&wq)[3][2]) {
     constexpr int HQ = CIN / 16, NH = 9 * HQ;  // half-taps per tap, per convolution
-    const int voff = lane_id() * 16, g = lane_id() >> 4;
-    int z = 0; asm volatile("" : "+v"(z));  // opaque zero: the 9 * NT * HQ swizzled addresses of a convolution must not be hoisted out of the task loop
+    const int voff = lane_id() * 16;
+    constexpr int PS = r32_ps(CIN);
+    int z = 0; asm volatile("" : "+v"(z));  // opaque zero: the 9 * NT operand addresses of a convolution must not be hoisted out of the task loop
     auto a_read = [&](int t, int tap, int h) {
         const int dr = tap / 3, dx = tap - 3 * dr;
-        const int p = abase[t] + z + dr * PW + dx;
-        return *(const f32x4 *)(img + p * CIN + 4 * ((HQ * g + h) ^ r32_swz<CIN>(p)));
+        return *(const f32x4 *)(img + abase[t] + z + ((dr * PW + dx) * PS + 4 * h));
     };
     f32x4 a[NT][HQ];
 #pragma unroll
@@ -2612,10 +2623,11 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
     const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX, WAVE_P = IMGW * IMGP + 1;  // pixels per wave incl. the dummy
+    constexpr int PS = r32_ps(CIN);
+    const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX, WAVE_P = IMGW * IMGP + 1;  // pixels per wave incl. the dummy
     int *ptab = (int *)rb_lds;     // [16 * NT] padded pixel index (within the wave's images) of pixel m of the wave's IMGW leaves
     float *sbias = rb_lds + 16 * NT;  // [4][32]
-    float *img = sbias + 128 + (size_t)wv * WAVE_P * CIN;
+    float *img = sbias + 128 + (size_t)wv * WAVE_P * PS;
     for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
         ptab[i] = i < MP ? im * IMGP + (r + 1) * PW + c + 1 : 0;
@@ -2623,7 +2635,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
     for (int i = threadIdx.x; i < 128; i += blockDim.x) sbias[i] = bias[i];
     {
         float4 *z4 = (float4 *)img;
-        for (int i = lane; i < WAVE_P * CIN / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // borders (and missing leaves of the last group) stay zero
+        for (int i = lane; i < WAVE_P * PS / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // borders (and missing leaves of the last group) stay zero
     }
     __syncthreads();
     const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
@@ -2634,9 +2646,9 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int m = t * 16 + n, pc = m < MP ? ptab[m] : IMGW * IMGP;  // rows past the wave's pixels: the dummy pixel
-        abase[t] = ptab[m < MP ? m : 0] - (PW + 1);
-        pdst[t][0] = pc * CIN + 4 * ((g) ^ r32_swz<CIN>(pc));       // channel quad g (channels 4 g ..) and
-        pdst[t][1] = pc * CIN + 4 * ((4 + g) ^ r32_swz<CIN>(pc));   // quad 4 + g (channels 16 + 4 g ..) of this lane's pixel
+        abase[t] = (ptab[m < MP ? m : 0] - (PW + 1)) * PS + 8 * g;  // top-left tap, input channels 8 g .. (r32_conv)
+        pdst[t][0] = pc * PS + 4 * g;         // channel quad g (channels 4 g ..) and
+        pdst[t][1] = pc * PS + 16 + 4 * g;    // quad 4 + g (channels 16 + 4 g ..) of this lane's pixel
     }
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 9 * CIN * 32 * 4, RS_BUF_FLAGS);
     constexpr int CONV_BYTES = 9 * CIN * 32 * 4;
@@ -2720,6 +2732,9 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 // max-pool out of an LDS staging copy of the convolution output (rows of 36 floats) that overwrites the (fully consumed) input
 // images.  Output: pooled x, channels-last, 16-byte stores.  Persistent waves; the next task's x is requested before this task's
 // convolution.
+#ifdef CP_STAMP
+__device__ unsigned long long g_cp_stamp[8];
+#endif
 template <int NT, int CIN>
 __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
@@ -2729,7 +2744,8 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX;
+    constexpr int PS = r32_ps(CIN);
+    const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX;
     const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
     int *ptab = (int *)rb_lds;            // [16 * NT] padded pixel index of pixel m
     int *pool = ptab + 16 * NT;           // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
@@ -2755,10 +2771,10 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int m = t * 16 + n, pc = m < MP ? ptab[m] : IMGW * IMGP;  // rows past the wave's pixels: the dummy pixel (behind the images)
-        abase[t] = ptab[m < MP ? m : 0] - (PW + 1);
+        abase[t] = (ptab[m < MP ? m : 0] - (PW + 1)) * PS + CIN / 4 * g;  // top-left tap, input channels CIN/4 * g .. (r32_conv)
         m_row[t] = m;
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * CIN + 4 * ((4 * q + g) ^ r32_swz<CIN>(pc));  // where this lane's q-th 16-byte piece of x goes: channel quad 4 q + g
+        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * PS + 4 * (4 * q + g);  // where this lane's q-th 16-byte piece of x goes: channel quad 4 q + g
     }
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 9 * CIN * 32 * 4, RS_BUF_FLAGS);
     const f32x4 ba = *(const f32x4 *)(bias + 4 * g), bb = *(const f32x4 *)(bias + 16 + 4 * g);
@@ -2776,6 +2792,12 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     load_x(leaf0);
     wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
     wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+#ifdef CP_STAMP  // diagnostic build: per-phase shader-clock totals of all waves, added into the first 64 bytes of `out` afterwards
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define CP_T(k) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; }
+#else
+#define CP_T(k)
+#endif
     for (; leaf0 < B; leaf0 += stride_leaves) {
         const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW);
 #pragma unroll
@@ -2785,7 +2807,9 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
         if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
         f32x4 acc[NT][2];
         lds_sync();
+        CP_T(0)
         r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
+        CP_T(1)
         lds_sync();
         // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows; rows past the
         // wave's pixels land behind the last real row (inside the wave's region: wave_floats covers 16 * NT rows)
@@ -2795,6 +2819,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
         }
         lds_sync();
+        CP_T(2)
         // pooling: 8 lanes x 4 channels per pooled pixel, window geometry from the workgroup's table.  Branch-free: a neighbour outside
         // the image reads the centre again (max with itself), so all nine 16-byte reads of a window are in flight together
         float4 *o4 = (float4 *)(out + (size_t)leaf0 * PP * 32);
@@ -2812,13 +2837,27 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)), fmaxf(fmaxf(v4.w, v5.w), fmaxf(fmaxf(v6.w, v7.w), v8.w)));
             o4[pq * 8 + cq] = m;
         }
+        CP_T(3)
         lds_sync();
         if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
             float4 *z4 = (float4 *)img;
             for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        CP_T(4)
     }
+#undef CP_T
+#ifdef CP_STAMP
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_cp_stamp[k], st_acc[k]);
+#endif
 }
+#ifdef CP_STAMP
+extern "C" int rp_debug_cp_stamp(unsigned long long *host8, int reset) {  // diagnostic builds only (not in include/rp_engine.h)
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_cp_stamp), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cp_stamp), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // The stage kernels for images that do not fit one wave (BASELINE configs[4]: 50x50 board -> 25x25x16, 13x13x32): one WORKGROUP per
@@ -2906,13 +2945,14 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
     const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if ((long long)blockIdx.x * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX, WG_P = IMGW * IMGP + 1;  // pixels incl. the dummy
+    constexpr int PS = r32_ps(CIN);
+    const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX, WG_P = IMGW * IMGP + 1;  // pixels incl. the dummy
     float *sbias = rb_lds;  // [4][32]
     float *img = sbias + 128;
     for (int i = threadIdx.x; i < 128; i += 64 * WAVES) sbias[i] = bias[i];
     {
         float4 *z4 = (float4 *)img;
-        for (int i = threadIdx.x; i < WG_P * CIN / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = threadIdx.x; i < WG_P * PS / 4; i += 64 * WAVES) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int n = lane & 15, g = lane >> 4;
     int abase[NT], pdst[NT][2];
@@ -2920,9 +2960,9 @@ __global__ void __launch_bounds__(64 * WAVES) k_resstage32_wg(const float *__res
     for (int t = 0; t < NT; ++t) {
         const int m = (wv * NT + t) * 16 + n, mm = m < MP ? m : 0, im = mm / PIX, pq = mm - im * PIX, r = pq / S_w, c = pq - r * S_w;
         const int pix = im * IMGP + (r + 1) * PW + c + 1, pc = m < MP ? pix : IMGW * IMGP;
-        abase[t] = pix - (PW + 1);
-        pdst[t][0] = pc * CIN + 4 * ((g) ^ r32_swz<CIN>(pc));
-        pdst[t][1] = pc * CIN + 4 * ((4 + g) ^ r32_swz<CIN>(pc));
+        abase[t] = (pix - (PW + 1)) * PS + 8 * g;
+        pdst[t][0] = pc * PS + 4 * g;
+        pdst[t][1] = pc * PS + 16 + 4 * g;
     }
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 4 * 9 * CIN * 32 * 4, RS_BUF_FLAGS);
     constexpr int CONV_BYTES = 9 * CIN * 32 * 4;
@@ -3007,7 +3047,8 @@ __global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__res
     const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if ((long long)blockIdx.x * IMGW >= B) return;
-    const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMGP = PH * PW, MP = IMGW * PIX;
+    constexpr int PS = r32_ps(CIN);
+    const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX;
     const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
     float *img = rb_lds;  // wg_floats: the padded input images + dummy pixel, later the staging rows
     {
@@ -3020,10 +3061,10 @@ __global__ void __launch_bounds__(64 * WAVES) k_convpool32_wg(const float *__res
     for (int t = 0; t < NT; ++t) {
         const int m = (wv * NT + t) * 16 + n, mm = m < MP ? m : 0, im = mm / PIX, pq = mm - im * PIX, r = pq / S_w, c = pq - r * S_w;
         const int pix = im * IMGP + (r + 1) * PW + c + 1, pc = m < MP ? pix : IMGW * IMGP;
-        abase[t] = pix - (PW + 1);
+        abase[t] = (pix - (PW + 1)) * PS + CIN / 4 * g;
         m_row[t] = m;
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * CIN + 4 * ((4 * q + g) ^ r32_swz<CIN>(pc));
+        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * PS + 4 * (4 * q + g);
     }
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 9 * CIN * 32 * 4, RS_BUF_FLAGS);
     const f32x4 ba = *(const f32x4 *)(bias + 4 * g), bb = *(const f32x4 *)(bias + 16 + 4 * g);
@@ -3781,8 +3822,8 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     if (B == 0) return RP_OK;
     if (H * W > (Cin == 16 ? 112 : 80)) {  // IMGW leaves per workgroup (k_convpool32_wg)
         const int PIXw = H * W, max_nt = Cin == 16 ? 10 : 8;  // tile rows per workgroup in units of 64: 40 tiles (Cin 16) / 32 tiles (Cin 32)
-        const size_t img_px = (size_t)(H + 2) * (W + 2);
-        auto floats_of = [&](int k) { return (std::max<size_t>((k * img_px + 1) * Cin, (size_t)16 * ((k * PIXw + 15) / 16) * 36) + 3) & ~(size_t)3; };
+        const size_t img_px = (size_t)r32_imgp(H, W);
+        auto floats_of = [&](int k) { return (std::max<size_t>((k * img_px + 1) * r32_ps(Cin), (size_t)16 * ((k * PIXw + 15) / 16) * 36) + 3) & ~(size_t)3; };
         int imgw = 0, nt = 0, waves = 4;
         long long best = -1;
         for (int k = 1; k * PIXw <= 64 * max_nt && floats_of(k) * sizeof(float) <= ctx->lds_per_cu; ++k) {
@@ -3811,11 +3852,11 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
         return RP_OK;
     }
     const int PIX = H * W, max_tiles = Cin == 16 ? 7 : 5;
-    const size_t img_pixels = (size_t)(H + 2) * (W + 2);
+    const size_t img_pixels = (size_t)r32_imgp(H, W);
     int imgw = (16 * max_tiles) / PIX;
     const int PPn = ((H + 1) / 2) * ((W + 1) / 2);
     // a wave's region holds its padded input images + the dummy pixel, later the staging copy of 16 * nt rows of 36 floats
-    auto wave_floats = [&](int k) { return (std::max<size_t>((k * img_pixels + 1) * Cin, (size_t)16 * ((k * PIX + 15) / 16) * 36) + 3) & ~(size_t)3; };
+    auto wave_floats = [&](int k) { return (std::max<size_t>((k * img_pixels + 1) * r32_ps(Cin), (size_t)16 * ((k * PIX + 15) / 16) * 36) + 3) & ~(size_t)3; };
     auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + (((size_t)k * PPn + 3) & ~(size_t)3) + 4 * wave_floats(k)) * sizeof(float); };
     while (imgw > 1 && lds_bytes(imgw) > 78 * 1024) --imgw;  // two workgroups per CU
     imgw = pick_leaves_per_wave(B, PIX, imgw);
@@ -3823,7 +3864,8 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     const size_t wf = wave_floats(imgw), lds = lds_bytes(imgw);
     if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_convpool32: a %dx%d image needs %zu bytes of LDS per workgroup, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
     const long long tasks = (B + imgw - 1) / imgw;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+    static const int cp_wgs = getenv("RP_CONVPOOL_WGS") ? atoi(getenv("RP_CONVPOOL_WGS")) : 2;  // resident workgroups per CU (experiments)
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)cp_wgs, ctx->lds_per_cu / lds));
     const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, (long long)ctx->n_cu * per_cu)), block(256);  // persistent waves
 #define CP_LAUNCH(NT_, CIN_)                                                                                                                         \
     {                                                                                                                                                \
@@ -3856,8 +3898,8 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
     if (B == 0) return RP_OK;
     const int PIX = H * W;
     if (PIX > 80) {  // IMGW leaves per workgroup (k_resstage32_wg): the group size with the best fill of 4 waves x nt tiles x 16 rows
-        const size_t img_px = (size_t)(H + 2) * (W + 2);
-        auto lds_of = [&](int k) { return (128 + (k * img_px + 1) * 32) * sizeof(float); };
+        const size_t img_px = (size_t)r32_imgp(H, W);
+        auto lds_of = [&](int k) { return (128 + (k * img_px + 1) * r32_ps(32)) * sizeof(float); };
         int imgw = 1, nt = 0, waves = 4;
         long long best = -1;
         for (int k = 1; k * PIX <= 512 && lds_of(k) <= ctx->lds_per_cu; ++k) {  // <= 32 tiles: 8 waves x 4 tiles
@@ -3883,8 +3925,8 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
         HIPCHK(ctx, hipGetLastError());
         return RP_OK;
     }
-    const size_t img_pixels = (size_t)(H + 2) * (W + 2);
-    auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + 128 + 4 * (k * img_pixels + 1) * 32) * sizeof(float); };
+    const size_t img_pixels = (size_t)r32_imgp(H, W);
+    auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + 128 + 4 * (k * img_pixels + 1) * r32_ps(32)) * sizeof(float); };
     int imgw_max = 80 / PIX;                                       // leaves per wave: at most 5 pixel tiles of 16
     while (imgw_max > 1 && lds_bytes(imgw_max) > 78 * 1024) --imgw_max;  // two workgroups per CU
     const int imgw = pick_leaves_per_wave(B, PIX, imgw_max);

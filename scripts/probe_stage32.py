@@ -30,3 +30,18 @@ torch.cuda.synchronize(); t = time.time()
 for _ in range(iters): fn()
 torch.cuda.synchronize(); dt = (time.time() - t) / iters
 print("%s B=%d: %.1f us per launch, %.1f TFLOP/s (%.3f of 157.3)" % (which, B, dt * 1e6, flops / dt / 1e12, flops / dt / 1e12 / 157.3))
+
+if os.environ.get("CP_STAMP") and which in ("cp16", "cp32"):  # RP_ENGINE_LIB = a -DCP_STAMP build with the rp_debug_cp_stamp export
+    import ctypes
+    import numpy as np
+    st = np.zeros(8, dtype=np.uint64)
+    torch.cuda.synchronize()
+    eng.L.rp_debug_cp_stamp(st.ctypes.data_as(ctypes.c_void_p), 1)
+    fn(); torch.cuda.synchronize()
+    eng.L.rp_debug_cp_stamp(st.ctypes.data_as(ctypes.c_void_p), 1)
+    st = st.astype(float)
+    names = ["stage x + sync", "conv", "sync + staging + sync", "pooling", "sync + re-zero"]
+    print("per leaf, s_memtime ticks summed over waves / leaves:")
+    for k in range(5):
+        print("  %-22s %8.1f" % (names[k], st[k] / B))
+    print("  total                  %8.1f" % (st[:5].sum() / B))
