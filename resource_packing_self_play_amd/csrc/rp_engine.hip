@@ -2568,12 +2568,11 @@ __host__ __device__ inline int r32_imgp(int H, int W) { return (H + 2) * (W + 1)
 // One 3x3 convolution CIN -> 32 over NT pixel tiles on the padded image.  abase[t]: FLOAT offset of this lane's first channel quad
 // (input channels CIN/4 * g ..) of the top-left tap of tile t's pixel of this lane; wq: fragments of half-taps (0, 1) on entry, of the
 // NEXT convolution's (byte offset fnext) on exit.
-template <int NT, int CIN>
+template <int NT, int CIN, int PS = r32_ps(CIN)>
 __device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
                                          f32x4 (&wq)[3][2]) {
     constexpr int HQ = CIN / 16, NH = 9 * HQ;  // half-taps per tap, per convolution
     const int voff = lane_id() * 16;
-    constexpr int PS = r32_ps(CIN);
     int z = 0; asm volatile("" : "+v"(z));  // opaque zero: the 9 * NT operand addresses of a convolution must not be hoisted out of the task loop
     auto a_read = [&](int t, int tap, int h) {
         const int dr = tap / 3, dx = tap - 3 * dr;
@@ -2729,9 +2728,13 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 
 // Entry of a 32-channel stage (ConvSequence.conv + max_pool2d(3, 2, 1), BinpackingNNet.py:34,39-40): 3x3 convolution
 // CIN -> 32 channels over the pixels of IMGW consecutive leaves (same transposed MFMA stream as above), bias, then the 3x3 / stride-2
-// max-pool out of an LDS staging copy of the convolution output (rows of 36 floats) that overwrites the (fully consumed) input
-// images.  Output: pooled x, channels-last, 16-byte stores.  Persistent waves; the next task's x is requested before this task's
-// convolution.
+// max-pool.  Round 3: the padded images have a pixel stride of 36 floats for either CIN, and the convolution output + bias (32
+// floats) is written IN PLACE over the interior pixels once the convolution has read them -- the pad cells are never written, so they
+// stay zero for the next task and the pooling reads its windows from the same padded geometry (a neighbour outside the image reads
+// the centre again).  The separate staging copy of the output (rows of 36 floats over the images) needed the whole region zeroed
+// again after every task: 3.0 k of a task's 45.8 k wave cycles (scripts/probe_stage32.py with a -DCP_STAMP build).  Output: pooled x,
+// channels-last, 16-byte stores.  Persistent waves; the next task's x is requested before this task's convolution.
+#define CP_PS 36
 #ifdef CP_STAMP
 __device__ unsigned long long g_cp_stamp[8];
 #endif
@@ -2740,15 +2743,15 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
                                                        float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
                                                        const int *__restrict__ nrows_dev) {
     constexpr int XQ = CIN / 16;  // 16-byte pieces of x per lane and tile
+    constexpr int PS = CP_PS;
     extern __shared__ __attribute__((aligned(16))) float rb_lds[];
     const int lane = lane_id(), wv = wave_in_block();
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
-    constexpr int PS = r32_ps(CIN);
     const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX;
     const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
     int *ptab = (int *)rb_lds;            // [16 * NT] padded pixel index of pixel m
-    int *pool = ptab + 16 * NT;           // [IMGW * PP]: centre pixel index | up << 16 | down << 17 | left << 18 | right << 19
+    int *pool = ptab + 16 * NT;           // [IMGW * PP]: padded index of the window's centre | up << 16 | down << 17 | left << 18 | right << 19
     float *img = rb_lds + 16 * NT + ((IMGW * PP + 3) & ~3) + (size_t)wv * wave_floats;
     for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
@@ -2756,25 +2759,23 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     }
     for (int i = threadIdx.x; i < IMGW * PP; i += blockDim.x) {
         int im = i / PP, pp = i - im * PP, pr = pp / Wp, px = pp - pr * Wp;
-        pool[i] = (im * PIX + 2 * pr * S_w + 2 * px) | ((pr > 0) << 16) | ((2 * pr + 1 < S_h) << 17) | ((px > 0) << 18) | ((2 * px + 1 < S_w) << 19);
+        pool[i] = (im * IMGP + (2 * pr + 1) * PW + 2 * px + 1) | ((pr > 0) << 16) | ((2 * pr + 1 < S_h) << 17) | ((px > 0) << 18) | ((2 * px + 1 < S_w) << 19);
     }
     {
         float4 *z4 = (float4 *)img;
-        for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // pad cells: zero once, never written again
     }
     __syncthreads();
     const long long stride_leaves = (long long)gridDim.x * 4 * IMGW;
     long long leaf0 = ((long long)blockIdx.x * 4 + wv) * IMGW;
     if (leaf0 >= B) return;
     const int n = lane & 15, g = lane >> 4;
-    int abase[NT], pin[NT][XQ], m_row[NT];
+    int abase[NT], pin[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int m = t * 16 + n, pc = m < MP ? ptab[m] : IMGW * IMGP;  // rows past the wave's pixels: the dummy pixel (behind the images)
         abase[t] = (ptab[m < MP ? m : 0] - (PW + 1)) * PS + CIN / 4 * g;  // top-left tap, input channels CIN/4 * g .. (r32_conv)
-        m_row[t] = m;
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) pin[t][q] = pc * PS + 4 * (4 * q + g);  // where this lane's q-th 16-byte piece of x goes: channel quad 4 q + g
+        pin[t] = pc * PS + 4 * g;  // this lane's pixel, channel quad g; quad 4 + g: + 16 floats (x of a 32-channel input, and the output)
     }
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void *)frag, 0, 9 * CIN * 32 * 4, RS_BUF_FLAGS);
     const f32x4 ba = *(const f32x4 *)(bias + 4 * g), bb = *(const f32x4 *)(bias + 16 + 4 * g);
@@ -2792,7 +2793,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     load_x(leaf0);
     wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
     wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
-#ifdef CP_STAMP  // diagnostic build: per-phase shader-clock totals of all waves, added into the first 64 bytes of `out` afterwards
+#ifdef CP_STAMP  // diagnostic build: per-phase shader-clock totals of all waves (rp_debug_cp_stamp)
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define CP_T(k) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; }
 #else
@@ -2801,22 +2802,21 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     for (; leaf0 < B; leaf0 += stride_leaves) {
         const int nimg = (int)(B - leaf0 < IMGW ? B - leaf0 : IMGW);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)  // x (no ReLU in front of a stage's first convolution) into the padded images
+        for (int t = 0; t < NT; ++t)  // x (no ReLU in front of a stage's first convolution) into the padded images (zeros past the task's end)
 #pragma unroll
-            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t][q]) = xv[t][q];
+            for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t] + 16 * q) = xv[t][q];
         if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
         f32x4 acc[NT][2];
         lds_sync();
         CP_T(0)
-        r32_conv<NT, CIN>(img, frs, 0, 0, PW, abase, acc, wq);
+        r32_conv<NT, CIN, PS>(img, frs, 0, 0, PW, abase, acc, wq);
         CP_T(1)
         lds_sync();
-        // staging[m][36]: convolution output + bias of pixel m (the wave's images back to back), 16-byte aligned rows; rows past the
-        // wave's pixels land behind the last real row (inside the wave's region: wave_floats covers 16 * NT rows)
+        // convolution output + bias over the interior pixels the convolution has read (rows past the wave's pixels: the dummy pixel)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            *(f32x4 *)(img + m_row[t] * 36 + 4 * g) = acc[t][0] + ba;
-            *(f32x4 *)(img + m_row[t] * 36 + 16 + 4 * g) = acc[t][1] + bb;
+            *(f32x4 *)(img + pin[t]) = acc[t][0] + ba;
+            *(f32x4 *)(img + pin[t] + 16) = acc[t][1] + bb;
         }
         lds_sync();
         CP_T(2)
@@ -2826,10 +2826,11 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
         for (int pq = lane >> 3; pq < nimg * PP; pq += 8) {
             const int info = pool[pq], ctr = info & 0xFFFF;
             const int up = (info >> 16) & 1, down = (info >> 17) & 1, left = (info >> 18) & 1, right = (info >> 19) & 1;
-            const float4 *row = (const float4 *)(img + ctr * 36) + cq;
-            const int ou = up ? -S_w : 0, od = down ? S_w : 0, ol = left ? -1 : 0, orr = right ? 1 : 0;
-            const float4 v0 = row[0], v1 = row[ol * 9], v2 = row[orr * 9], v3 = row[ou * 9], v4 = row[(ou + ol) * 9], v5 = row[(ou + orr) * 9],
-                         v6 = row[od * 9], v7 = row[(od + ol) * 9], v8 = row[(od + orr) * 9];
+            const float4 *row = (const float4 *)(img + ctr * PS) + cq;
+            const int ou = up ? -PW : 0, od = down ? PW : 0, ol = left ? -1 : 0, orr = right ? 1 : 0;
+            constexpr int Q = PS / 4;
+            const float4 v0 = row[0], v1 = row[ol * Q], v2 = row[orr * Q], v3 = row[ou * Q], v4 = row[(ou + ol) * Q], v5 = row[(ou + orr) * Q],
+                         v6 = row[od * Q], v7 = row[(od + ol) * Q], v8 = row[(od + orr) * Q];
             float4 m;
             m.x = fmaxf(fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x)), fmaxf(fmaxf(v4.x, v5.x), fmaxf(fmaxf(v6.x, v7.x), v8.x)));
             m.y = fmaxf(fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y)), fmaxf(fmaxf(v4.y, v5.y), fmaxf(fmaxf(v6.y, v7.y), v8.y)));
@@ -2838,11 +2839,7 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
             o4[pq * 8 + cq] = m;
         }
         CP_T(3)
-        lds_sync();
-        if (leaf0 + stride_leaves < B) {  // the staging copy overwrote the padded images: borders back to zero for the next task
-            float4 *z4 = (float4 *)img;
-            for (int i = lane; i < wave_floats / 4; i += 64) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        lds_sync();  // the windows have been read: the next task's x may overwrite the interior pixels
         CP_T(4)
     }
 #undef CP_T
@@ -3855,8 +3852,8 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
     const size_t img_pixels = (size_t)r32_imgp(H, W);
     int imgw = (16 * max_tiles) / PIX;
     const int PPn = ((H + 1) / 2) * ((W + 1) / 2);
-    // a wave's region holds its padded input images + the dummy pixel, later the staging copy of 16 * nt rows of 36 floats
-    auto wave_floats = [&](int k) { return (std::max<size_t>((k * img_pixels + 1) * r32_ps(Cin), (size_t)16 * ((k * PIX + 15) / 16) * 36) + 3) & ~(size_t)3; };
+    // a wave's region holds its padded images at 36 floats per pixel (x, then the convolution output in place) + the dummy pixel
+    auto wave_floats = [&](int k) { return (size_t)(k * img_pixels + 1) * CP_PS; };
     auto lds_bytes = [&](int k) { return ((size_t)16 * ((k * PIX + 15) / 16) + (((size_t)k * PPn + 3) & ~(size_t)3) + 4 * wave_floats(k)) * sizeof(float); };
     while (imgw > 1 && lds_bytes(imgw) > 78 * 1024) --imgw;  // two workgroups per CU
     imgw = pick_leaves_per_wave(B, PIX, imgw);
