@@ -1237,19 +1237,24 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_moves(DP p) {
 
 // np.sum(Ps[s]) over the dense A-vector in NumPy's pairwise order (MCTS_bpp.py:90,100).  mode 0:
 // x[a] = float64(pi[a]) * valid[a]; mode 1 (fallback): x[a] = float64(pi[a]) * valid[a] + valid[a].
-__device__ __forceinline__ double prior_term(const float *pi, const u32 *vmask, int a, int mode) {
-    double valid = (double)((vmask[a >> 5] >> (a & 31)) & 1u);
-    double x = (double)pi[a] * valid;
-    return mode ? x + valid : x;
+// One element of Ps[s] = pi * valids (float64 in the reference: float32 times int64).  The product is pi or (+-)0 -- exactly a
+// float32 -- so the staged terms are FLOATS (round 3: half the LDS of k_commit's term buffer, 4 -> 7 workgroups per CU) and widen on
+// the way out; the fallback's `+ valids` (MCTS_bpp.py:93-100) is added in float64 where the chain reads the term.
+__device__ __forceinline__ float prior_term_f(const float *pi, const u32 *vmask, int a) {
+    return pi[a] * (float)((vmask[a >> 5] >> (a & 31)) & 1u);  // x * 1 = x, x * 0 = (+-)0, NaN / inf * 0 = NaN: as the float64 product
+}
+__device__ __forceinline__ double term_at(const float *sterm, const u32 *vmask, int i, int a, int mode) {
+    const double x = (double)sterm[i];
+    return mode ? x + (double)((vmask[a >> 5] >> (a & 31)) & 1u) : x;
 }
 #define TERM_CHUNK 1024  /* 8 leaves x <= 128 elements */
-__device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmask, double *sleaf, double *sterm, int mode) {
+__device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmask, double *sleaf, float *sterm, int mode) {
     const int lane = lane_id(), j = lane & 7;
     for (int lb = 0; lb < p.n_leaves; lb += 8) {
         // the 8 leaves of this pass cover one contiguous element range: build its float64 terms with coalesced loads ...
         const int lend = (lb + 8 < p.n_leaves ? lb + 8 : p.n_leaves) - 1;
         const int glo = p.leaf_lo[lb], ghi = p.leaf_lo[lend] + p.leaf_n[lend];
-        for (int a = glo + lane; a < ghi; a += 64) sterm[a - glo] = prior_term(pi, vmask, a, mode);
+        for (int a = glo + lane; a < ghi; a += 64) sterm[a - glo] = prior_term_f(pi, vmask, a);
         wave_sync();
         // ... then every (leaf, accumulator) pair runs its sequential chain out of LDS
         int l = lb + (lane >> 3);
@@ -1258,18 +1263,18 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
         double res = 0.0;
         if (n >= 8) {
             int n8 = n - (n & 7);
-            double r = sterm[lo + j];
-            for (int i = 8 + j; i < n8; i += 8) r = r + sterm[lo + i];
+            double r = term_at(sterm, vmask, lo + j, glo + lo + j, mode);
+            for (int i = 8 + j; i < n8; i += 8) r = r + term_at(sterm, vmask, lo + i, glo + lo + i, mode);
             double s1 = r + __shfl_down(r, 1);     // r0+r1, r2+r3, ...
             double s2 = s1 + __shfl_down(s1, 2);   // (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
             double s3 = s2 + __shfl_down(s2, 4);
             res = s3;
             if (j == 0)
-                for (int i = n8; i < n; ++i) res = res + sterm[lo + i];
+                for (int i = n8; i < n; ++i) res = res + term_at(sterm, vmask, lo + i, glo + lo + i, mode);
         } else {
             if (act && j == 0) {
                 res = -0.0;
-                for (int i = 0; i < n; ++i) res = res + sterm[lo + i];
+                for (int i = 0; i < n; ++i) res = res + term_at(sterm, vmask, lo + i, glo + lo + i, mode);
             }
         }
         if (act && j == 0) sleaf[l] = res;
@@ -1287,7 +1292,7 @@ __device__ double numpy_masked_sum(const DP &p, const float *pi, const u32 *vmas
 // positive, else the sum of the uniform fallback pi * valids + valids.  The legal moves' float32 pi go to `pi_out`.
 // *best_k_out: the legal move with the largest pi, lowest index among equals (Tree::rescan_best: the first PUCT candidate of the new node).
 __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, float *pi_out, u32 n_valid, u32 *vmask, double *sleaf,
-                               double *sterm, bool *fallback, u32 *best_k_out = nullptr) {
+                               float *sterm, bool *fallback, u32 *best_k_out = nullptr) {
     const int lane = lane_id();
     const int words = (p.A + 31) >> 5;
     for (int w = lane; w < words; w += 64) vmask[w] = 0u;
@@ -1329,14 +1334,17 @@ __device__ double masked_prior(const DP &p, const float *pi, const u16 *act, flo
 // exp(x - max) / sum, the sum taken lane-wise then across lanes (the policy tolerance is 1e-5, not bit equality with one library).
 template <typename row_t, bool LOGITS>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const float *pi, const float *vv) {
-    __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
-    __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [WAVES_PER_BLOCK][min(A, TERM_CHUNK)] float64 terms, then (LOGITS) [WAVES_PER_BLOCK][A] floats
+    // LDS per wave, all of it sized by the action space (commit_lds_bytes): n_leaves float64 block sums, min(A, TERM_CHUNK) float32
+    // terms, (LOGITS) A float32 probabilities, ceil(A / 32) mask words -- 5.3 KB per wave at A = 640, so the workgroups per CU are
+    // bounded by registers (7 waves per SIMD), not by LDS (round 2 / 3: 9.7 KB per wave with float64 terms and worst-case tables: 4)
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int g = blockIdx.x * WAVES_PER_BLOCK + wave_in_block(), lane = lane_id(), wv = wave_in_block();
     if (g >= p.G) return;
-    const int tchunk = p.A < TERM_CHUNK ? p.A : TERM_CHUNK;
-    double *s_term_w = s_dyn + (size_t)wv * tchunk;
-    float *s_soft = (float *)(s_dyn + (size_t)WAVES_PER_BLOCK * tchunk);
+    const int tchunk = p.A < TERM_CHUNK ? p.A : TERM_CHUNK, mwords = ((p.A + 31) >> 5) + 1;
+    double *s_leaf_w = s_dyn + (size_t)wv * p.n_leaves;
+    float *s_term_w = (float *)(s_dyn + (size_t)WAVES_PER_BLOCK * p.n_leaves) + (size_t)wv * tchunk;
+    float *s_soft = (float *)(s_dyn + (size_t)WAVES_PER_BLOCK * p.n_leaves) + (size_t)WAVES_PER_BLOCK * tchunk;
+    u32 *s_mask_w = (u32 *)(s_soft + (LOGITS ? (size_t)WAVES_PER_BLOCK * p.A : 0)) + (size_t)wv * mwords;
     // One wave per SLOT: the slot's phase, leaf, path and evaluator row are requested together (one memory round trip) -- a wave per
     // evaluator ROW first had to fetch the row's slot (eval_slot[b]) and only then the slot's state.  Slots that wait for nothing leave.
     const int phase = p.phase[g];
@@ -1381,7 +1389,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_commit(DP p, const flo
     }
     bool fb;
     u32 bk = 0xFFFFu;  // kept for nodes whose legal moves take more than one pass of the wave (Tree::select_edge)
-    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask[wv], s_leaf[wv], s_term_w, &fb, hd.n_valid > 64u ? &bk : nullptr);
+    double norm = masked_prior(p, row, t.pAct + hd.prior_off, t.pPi + hd.prior_off, hd.n_valid, s_mask_w, s_leaf_w, s_term_w, &fb, hd.n_valid > 64u ? &bk : nullptr);
     if (lane == 0) {  // Ps[s] (as pi + normaliser), Vs[s] = valids, Ns[s] = 0 (:89-103)
         hd.flags |= (u8)(HF_EXPANDED | (fb ? HF_FALLBACK : 0u)); hd.ns = 0; hd.norm = norm; hd.best_k = (u16)bk;
         t.hdr[node] = hd;
@@ -2085,7 +2093,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_selftest_prior(DP p, l
                                                                           float *pi_scratch) {
     __shared__ u32 s_mask[WAVES_PER_BLOCK][MAX_MASK_WORDS];
     __shared__ double s_leaf[WAVES_PER_BLOCK][MAX_LEAVES];
-    __shared__ double s_term[WAVES_PER_BLOCK][TERM_CHUNK];
+    __shared__ float s_term[WAVES_PER_BLOCK][TERM_CHUNK];
     const long long b = (long long)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     if (b >= B) return;
     const int lane = lane_id(), wv = wave_in_block();
@@ -3931,7 +3939,8 @@ extern "C" int rp_nn_resstage32(rp_ctx *ctx, const float *x_dev, const float *fr
     const size_t lds = lds_bytes(imgw);
     if (lds > ctx->lds_per_cu) return fail(ctx, RP_ERR_ARG, "rp_nn_resstage32: a %dx%d image needs %zu bytes of LDS per workgroup, the device has %zu per CU", H, W, lds, ctx->lds_per_cu);
     const long long tasks = (B + imgw - 1) / imgw;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_per_cu / lds));
+    static const int rs32_wgs = getenv("RP_STAGE32_WGS") ? atoi(getenv("RP_STAGE32_WGS")) : 2;  // resident workgroups per CU (experiments)
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)rs32_wgs, ctx->lds_per_cu / lds));
     const dim3 grid((unsigned)std::min<long long>((tasks + 3) / 4, (long long)ctx->n_cu * per_cu)), block(256);  // persistent waves
 #define RS_LAUNCH(NT_)                                                                                                                              \
     case NT_:                                                                                                                                       \
@@ -3973,7 +3982,8 @@ extern "C" int rp_leaf_states(rp_ctx *ctx, int32_t max_rows, uint64_t *rows_out,
 static int launch_commit(rp_ctx *ctx, const float *pi_dev, const float *v_dev, bool logits) {
     const DP &d = ctx->d;
     const dim3 grid(grid_for(d.G)), block(64 * WAVES_PER_BLOCK);  // one wave per slot; waiting slots find their evaluator row in game_row
-    const size_t lds = (size_t)WAVES_PER_BLOCK * std::min(d.A, TERM_CHUNK) * sizeof(double) + (logits ? (size_t)WAVES_PER_BLOCK * d.A * sizeof(float) : 0);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * ((size_t)d.n_leaves * sizeof(double) + (size_t)std::min(d.A, TERM_CHUNK) * sizeof(float) +
+                                                 (logits ? (size_t)d.A * sizeof(float) : 0) + (size_t)(((d.A + 31) >> 5) + 1) * sizeof(u32));
     if (logits) {
         if (ctx->row64) hipLaunchKernelGGL((k_commit<u64, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
         else hipLaunchKernelGGL((k_commit<u32, true>), grid, block, lds, ctx->stream, d, pi_dev, v_dev);
