@@ -1526,8 +1526,11 @@ __global__ void __launch_bounds__(256) k_stem_tables(int N, const float *w /*[16
 // loop over leaves -- the table rows a wave touches differ from lane to lane, which made the L1/L2 round trip of every
 // 64-byte row the kernel's critical path.  Larger tables (N > 40) stay in L2.
 #define STEM_NEG_INF ((int)0x80000000)  /* an output outside the image: never added to, loses every maximum */
+#ifndef STEM_WAVES
+#define STEM_WAVES 3  /* workgroups per CU (51 KB table each at N = 32) = waves per SIMD: the register budget (168) and the persistent grid follow it */
+#endif
 template <typename row_t, bool T_LDS>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows, int nhwc) {
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, STEM_WAVES) k_leaf_stem(DP p, float *out, float *out_relu, long long capacity_rows, int nhwc) {
     extern __shared__ __attribute__((aligned(16))) int4 sT4[];
     const int lane = lane_id();
     if (T_LDS) {
@@ -1611,6 +1614,41 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
                 row_t v = __shfl(myrow, rr & 63);
                 rw[q] = (live && rr >= 0 && rr < p.H) ? v : (row_t)0;
             }
+            // CORNER PHASE (round 3, first pass only).  The item loop below costs 16 ds_read_b128 per item whatever the item's size, and
+            // the kernel is bound by exactly that: 628 LDS instructions per 20x20 leaf at ~5 LDS cycles each on a CU's one LDS pipe
+            // (profiles/r03_f_pmc_sq_own_kernels.md).  But an item is a rectangle anchored at the origin, and most are small: one whose
+            // height and width are below CR x CC (8 x 8 where the image allows) reaches outputs of the top-left CR x CC pixels only.
+            // Those items are summed in a layout of their own -- lane = ONE output pixel of the corner (row lane >> 3, column lane & 7),
+            // 16 accumulators, 4 reads per item instead of 16 -- and the corner's sums are then handed to the lanes that own its 2x2
+            // blocks (64 shuffles, about two items' worth of LDS time; taken for four small items or more).  Integer sums commute:
+            // the result is bit-identical to the plain loop.
+            const int zrow = p.N * 25;
+            int cacc[STEM_C];
+            bool cornered = false;          // uniform
+            u64 small[2] = {0ull, 0ull};
+            int CR = 0, CC = 0;
+            if (pass == 0) {
+                const int nprf = min(4, 60 / p.Wp + 1);  // pooled rows whose first four pixels sit in this pass's 64 lanes
+                CR = min(8, 2 * nprf); CC = min(8, 2 * min(4, p.Wp));
+                small[0] = __ballot((wh_lo >> 8) < CR && (wh_lo & 255) < CC) & rem0;
+                small[1] = p.N > 64 ? (__ballot((wh_hi >> 8) < CR && (wh_hi & 255) < CC) & rem1) : 0ull;
+                cornered = __popcll(small[0]) + __popcll(small[1]) >= 4;
+            }
+            if (cornered) {
+                const int cr = lane >> 3, cx = lane & 7, r0c = cr == 0 ? 2 : 0, c0c = cx == 0 ? 2 : 0;
+#pragma unroll
+                for (int o = 0; o < STEM_C; ++o) cacc[o] = 0;
+                for (int half = 0; half < 2; ++half)
+                for (u64 m = small[half]; m; m &= m - 1) {
+                    const int il = __ffsll((long long)m) - 1, i = il + 64 * half;
+                    const int whi = half ? __builtin_amdgcn_readlane(wh_hi, il) : __builtin_amdgcn_readlane(wh_lo, il);
+                    const int dr = (whi >> 8) - cr, dc = (whi & 255) - cx;  // >= 0: output (cr, cx) has a tap inside the rectangle
+                    const int trow = (dr >= 0 && dc >= 0) ? i * 25 + (min(dr, 2) + r0c) * 5 + min(dc, 2) + c0c : zrow;
+                    const int4 *tt = T_LDS ? (sT4 + trow * (STEM_C / 4)) : ((const int4 *)p.stemT + (size_t)trow * (STEM_C / 4));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { int4 v = tt[q]; cacc[4 * q] += v.x; cacc[4 * q + 1] += v.y; cacc[4 * q + 2] += v.z; cacc[4 * q + 3] += v.w; }
+                }
+            }
             int acc[4][STEM_C];  // fixed point; outputs outside the image (odd sizes, idle lanes) start at "-inf" and stay there: the pool needs no selects
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1637,12 +1675,23 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) k_leaf_stem(DP p, float 
             // Branch-free per item: an output's class against the rectangle is min(extent - coordinate, 2) (+ 2 in row / column 0); an
             // output the rectangle does not reach reads the all-zero row behind the table instead of being skipped -- no exec-mask
             // juggling around the four outputs, and the 16 loads of an item are independent of each other.
-            const int r0b = ra == 0 ? 2 : 0, c0b = xa == 0 ? 2 : 0, zrow = p.N * 25;
+            const int r0b = ra == 0 ? 2 : 0, c0b = xa == 0 ? 2 : 0;
+            if (cornered) {  // the corner's sums go to the lanes that own its 2x2 blocks (pass 0: lane = pooled pixel pr * Wp + px)
+                const bool mine = live && ra < CR && xa < CC;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int src = ((ra + (j >> 1)) * 8 + xa + (j & 1)) & 63;
+                    const bool okj = mine && ((j >> 1) ? rbok : true) && ((j & 1) ? xbok : true);
+#pragma unroll
+                    for (int o = 0; o < STEM_C; ++o) { const int v = __shfl(cacc[o], src); acc[j][o] += okj ? v : 0; }
+                }
+            }
             // The items worth a look in this pass: unplaced (a placed item's plane is zero) and tall enough to reach the pass's first image
             // row -- an item's rectangle is anchored at the origin, so every pass below its height skips it without touching it (at the
             // 50x50 board 12 of 16 passes lie below nearly every item; testing all 128 items in each cost as much as the adds).
             const int thr = 2 * (base / p.Wp);
-            const u64 cand[2] = {__ballot((wh_lo >> 8) >= thr) & rem0, p.N > 64 ? (__ballot((wh_hi >> 8) >= thr) & rem1) : 0ull};
+            const u64 cand[2] = {__ballot((wh_lo >> 8) >= thr) & rem0 & (cornered ? ~small[0] : ~0ull),
+                                 p.N > 64 ? (__ballot((wh_hi >> 8) >= thr) & rem1 & (cornered ? ~small[1] : ~0ull)) : 0ull};
             for (int half = 0; half < 2; ++half)
             for (u64 m = cand[half]; m; m &= m - 1) {
                 const int il = __ffsll((long long)m) - 1, i = il + 64 * half;
@@ -3677,7 +3726,7 @@ extern "C" int rp_leaf_stem(rp_ctx *ctx, float *out_dev, float *out_relu_dev, in
     const size_t t_bytes = (size_t)(d.N * 25 + 1) * STEM_C * sizeof(int);  // the item table and its zero row
     const bool t_lds = t_bytes <= 64 * 1024;
     // LDS form: persistent workgroups, 3 per CU (3 x 51 KB of LDS at N = 32), a wave per leaf; L2 form: a workgroup per leaf
-    const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? ctx->n_cu * 3 : 1 << 20);
+    const int grid = (int)std::min<long long>(t_lds ? grid_for(rows) : rows, t_lds ? ctx->n_cu * STEM_WAVES : 1 << 20);
     if (ctx->row64) {
         if (t_lds) hipLaunchKernelGGL((k_leaf_stem<u64, true>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), t_bytes, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
         else hipLaunchKernelGGL((k_leaf_stem<u64, false>), dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, ctx->stream, d, out_dev, out_relu_dev, (long long)capacity_rows, (int)(channels_last != 0));
