@@ -2443,18 +2443,46 @@ __device__ __forceinline__ f32x4 rs_load_b(__amdgpu_buffer_rsrc_t rsrc, int voff
 __device__ __forceinline__ f32x4 rs_load_x(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, RS_STREAM_AUX));
 }
-// One 3x3 convolution 16 -> 16 over NT pixel tiles.  wq: weight fragments of taps (tap, tap + 1) on entry -- taps 0 and 1 of the NEXT
-// convolution (byte offset fnext) on exit.
-template <int NT>
+// TAIL TILE (round 3).  100 pixels of a 10x10 image are six tiles of 16 and FOUR pixels: as a seventh 16-column tile they cost a full
+// tile's matrix-pipe time for a quarter of its columns (tile fill 0.893).  v_mfma_f32_4x4x1_16B_f32 multiplies sixteen independent
+// 4x1 by 1x4 blocks per instruction (lane l: block l >> 2, A row / B column l & 3; result register r of lane l = A[4 (l >> 2) + r] *
+// B[l], scripts/probe_mfma4x4.hip) in 8 matrix-pipe cycles instead of 32.  Block (cg, kk) = (l >> 4, (l >> 2) & 3) takes output channels
+// 4 cg .. 4 cg + 3 of the four tail pixels over the input channels 4 kk .. 4 kk + 3: A = W[4 cg + (l & 3)][4 kk + q][tap] -- which is
+// the ordinary fragment of lane (4 cg + (l & 3)) + 16 kk, so the same buffer serves --, B = x[pixel l & 3][4 kk + q][tap], q = 0..3:
+// one ds_read_b128 and four 8-cycle MFMAs per tap (288 instead of 1 152 matrix-pipe cycles per convolution).  The four kk blocks of
+// a channel group hold partial sums over their input-channel slices; they meet in the epilogue (two DPP row rotations), after which lane
+// l holds channels 4 (l >> 4) .. + 3 of tail pixel l & 3 -- the accumulator layout of the ordinary tiles, so bias, ReLU, skip operands
+// and the 16-byte stores are the same code.  (The tail pixels' sums associate differently from the other pixels': float32 either way.)
+struct RsTail {
+    int abase;     // float offset of this lane's tail pixel (l & 3): top-left tap, channel quad kk
+    int voff;      // byte offset of this lane's weight fragment inside a tap's 1 KB: 16 x ((4 cg + (l & 3)) + 16 kk)
+    f32x4 acc;
+    f32x4 wq[3];
+};
+template <int CTRL> __device__ __forceinline__ float rs_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ f32x4 rs_tail_sum(f32x4 v) {  // sum over the four kk blocks of a channel group (lanes l, l + 4, l + 8, l + 12 of a row)
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float s = v[k] + rs_dpp<0x128>(v[k]); r[k] = s + rs_dpp<0x124>(s); }  // row_ror:8, row_ror:4
+    return r;
+}
+// One 3x3 convolution 16 -> 16 over NT pixel tiles (+ the tail tile).  wq: weight fragments of taps (tap, tap + 1) on entry -- taps 0 and
+// 1 of the NEXT convolution (byte offset fnext) on exit.
+template <int NT, bool TAIL = false>
 __device__ __forceinline__ void rs_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT],
-                                        f32x4 (&wq)[3]) {
+                                        f32x4 (&wq)[3], RsTail *tl = nullptr) {
     const int voff = lane_id() * 16;
-    f32x4 a[NT];
+    f32x4 a[NT], at = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; a[t] = *(const f32x4 *)(img + abase[t]); }
+    if (TAIL) { tl->acc = (f32x4){0.f, 0.f, 0.f, 0.f}; at = *(const f32x4 *)(img + tl->abase); }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        wq[(tap + 2) % 3] = rs_load_b(frs, voff, tap + 2 < 9 ? fbase + (tap + 2) * 1024 : fnext + (tap + 2 - 9) * 1024);
+        const int fo = tap + 2 < 9 ? fbase + (tap + 2) * 1024 : fnext + (tap + 2 - 9) * 1024;
+        wq[(tap + 2) % 3] = rs_load_b(frs, voff, fo);
+        if (TAIL) tl->wq[(tap + 2) % 3] = rs_load_b(frs, tl->voff, fo);
         const f32x4 w = wq[tap % 3];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2471,6 +2499,13 @@ __device__ __forceinline__ void rs_conv(const float *img, __amdgpu_buffer_rsrc_t
             if (tap + 1 < 9) a[t] = *(const f32x4 *)(img + abase[t] + off);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (TAIL) {
+            const f32x4 wt = tl->wq[tap % 3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tl->acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wt[q], at[q], tl->acc, 0, 0, 0);
+            if (tap + 1 < 9) at = *(const f32x4 *)(img + tl->abase + off);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 __device__ __forceinline__ f32x4 rs_relu(f32x4 v) { return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
@@ -2478,7 +2513,8 @@ __device__ __forceinline__ f32x4 rs_relu(f32x4 v) { return (f32x4){fmaxf(v[0], 0
 // are set up once; the next task's x is staged into the image right behind this task's output stores and the x after that is
 // requested then, so it lands in registers during the four convolutions.  Nothing in the task loop branches on data: rows past the
 // wave's pixels write to a dummy pixel, rows past the task's end read zeros and their stores are dropped by the buffer bounds check.
-template <int NT>
+// TAIL: the wave's pixels are NT tiles of 16 + a tail of up to four (rs_conv).
+template <int NT, bool TAIL = false>
 __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                            float *__restrict__ out, float *__restrict__ out_relu, long long B, int S_h, int S_w, int IMGW,
                                                            const int *__restrict__ nrows_dev) {
@@ -2489,9 +2525,10 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     if (nrows_dev) { const long long n = *nrows_dev; if (n < B) B = n; }  // only the first *nrows_dev rows hold leaves (compact rows)
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = S_w + 2, PH = S_h + 2, PIX = S_h * S_w, IMG = PH * PW * RS_STRIDE, MP = IMGW * PIX, WAVE_F = IMGW * IMG + RS_STRIDE;
-    int *ptab = (int *)rb_lds;  // [16 * NT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
-    float *img = rb_lds + 16 * NT + (size_t)wv * WAVE_F;
-    for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+    constexpr int NTT = NT + (TAIL ? 1 : 0);  // table rows and LDS are sized for whole tiles
+    int *ptab = (int *)rb_lds;  // [16 * NTT] LDS offset (within the wave's images) of channel 0 of pixel m of the wave's IMGW leaves
+    float *img = rb_lds + 16 * NTT + (size_t)wv * WAVE_F;
+    for (int i = threadIdx.x; i < 16 * NTT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
         ptab[i] = i < MP ? im * IMG + ((r + 1) * PW + c + 1) * RS_STRIDE : 0;
     }
@@ -2518,17 +2555,32 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
     const int rowoff = n * 64 + g * 16;  // byte offset of (pixel n, channel quad g) in a tile's 1 KB of [pixel][16] floats
     auto task_bytes = [&](long long l0) { return (int)(B - l0 < IMGW ? B - l0 : IMGW) * PIX * 64; };
     f32x4 xv[NT], xs[NT], wq[3];
+    // tail tile: lane = (channel group g = lane >> 4, input-channel slice kk = (lane >> 2) & 3, tail pixel lane & 3)
+    RsTail tl;
+    f32x4 xvt = (f32x4){0.f, 0.f, 0.f, 0.f}, xst = xvt;
+    const int kk = (lane >> 2) & 3, mt = 16 * NT + (lane & 3);
+    int pdst_t = 0;
+    const int rowoff_t = (lane & 3) * 64 + g * 16;  // (tail pixel, channel quad g) inside the tail's 256 bytes behind the NT tiles
+    if (TAIL) {
+        const int pc = ptab[mt < MP ? mt : 0];
+        tl.abase = pc - (PW + 1) * RS_STRIDE + 4 * kk;
+        tl.voff = ((4 * g + (lane & 3)) + 16 * kk) * 16;
+        pdst_t = (mt < MP ? pc : IMGW * IMG) + 4 * g;
+    }
     auto load_x = [&](long long l0) {  // request a task's x in accumulator layout, zeros past its end
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * 16), 0, task_bytes(l0), RS_BUF_FLAGS);
 #pragma unroll
         for (int t = 0; t < NT; ++t) xv[t] = rs_load_x(rs, rowoff, t * 1024);
+        if (TAIL) xvt = rs_load_x(rs, rowoff_t, NT * 1024);
     };
     auto stage_x = [&]() {  // xs = x (skip operand of block 0); relu(x) into the padded images
 #pragma unroll
         for (int t = 0; t < NT; ++t) { xs[t] = xv[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xv[t]); }
+        if (TAIL) { xst = xvt; *(f32x4 *)(img + pdst_t) = rs_relu(xvt); }  // the four kk lanes of a (pixel, quad) write the same 16 bytes
     };
     load_x(leaf0);
     wq[0] = rs_load_b(frs, lane * 16, 0); wq[1] = rs_load_b(frs, lane * 16, 1024);
+    if (TAIL) { tl.wq[0] = rs_load_b(frs, tl.voff, 0); tl.wq[1] = rs_load_b(frs, tl.voff, 1024); }
     stage_x();
     if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
 #ifdef RS_STAMP
@@ -2548,35 +2600,44 @@ __global__ void __launch_bounds__(256, RS_LB) k_resstage16(const float *__restri
         f32x4 acc[NT];
         lds_sync();
         RS_T(1)
-        rs_conv<NT>(img, frs, 0, 9 * 1024, PW, abase, acc, wq);              // block 0, conv0
+        rs_conv<NT, TAIL>(img, frs, 0, 9 * 1024, PW, abase, acc, wq, &tl);              // block 0, conv0
         RS_T(2)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[0]);
+        if (TAIL) *(f32x4 *)(img + pdst_t) = rs_relu(rs_tail_sum(tl.acc) + bias4[0]);
         lds_sync();
         RS_T(3)
-        rs_conv<NT>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq);      // block 0, conv1 (+ skip x)
+        rs_conv<NT, TAIL>(img, frs, 9 * 1024, 18 * 1024, PW, abase, acc, wq, &tl);      // block 0, conv1 (+ skip x)
         RS_T(4)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { xs[t] = (acc[t] + bias4[1]) + xs[t]; *(f32x4 *)(img + pdst[t]) = rs_relu(xs[t]); }  // y1, kept as block 1's skip operand
+        if (TAIL) { xst = (rs_tail_sum(tl.acc) + bias4[1]) + xst; *(f32x4 *)(img + pdst_t) = rs_relu(xst); }
         lds_sync();
         RS_T(5)
-        rs_conv<NT>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq);     // block 1, conv0
+        rs_conv<NT, TAIL>(img, frs, 18 * 1024, 27 * 1024, PW, abase, acc, wq, &tl);     // block 1, conv0
         RS_T(6)
 #pragma unroll
         for (int t = 0; t < NT; ++t) *(f32x4 *)(img + pdst[t]) = rs_relu(acc[t] + bias4[2]);
+        if (TAIL) *(f32x4 *)(img + pdst_t) = rs_relu(rs_tail_sum(tl.acc) + bias4[2]);
         lds_sync();
         RS_T(7)
-        rs_conv<NT>(img, frs, 27 * 1024, 0, PW, abase, acc, wq);             // block 1, conv1 (+ skip y1)
+        rs_conv<NT, TAIL>(img, frs, 27 * 1024, 0, PW, abase, acc, wq, &tl);             // block 1, conv1 (+ skip y1)
         RS_T(8)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = (acc[t] + bias4[3]) + xs[t];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[t]), ors, rowoff, t * 1024, RS_STREAM_AUX);
         }
+        f32x4 acct = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (TAIL) {
+            acct = (rs_tail_sum(tl.acc) + bias4[3]) + xst;
+            if (kk == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acct), ors, rowoff_t, NT * 1024, RS_STREAM_AUX);
+        }
         if (want_relu) {  // uniform: relu(result) for the next layer's input, a second set of 16-byte stores
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(out_relu + (size_t)leaf0 * PIX * 16), 0, nbytes, RS_BUF_FLAGS);
 #pragma unroll
             for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acc[t])), rrs, rowoff, t * 1024, RS_STREAM_AUX);
+            if (TAIL && kk == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs_relu(acct)), rrs, rowoff_t, NT * 1024, RS_STREAM_AUX);
         }
         RS_T(9)
         // the image is free (the last convolution has read it): stage the next task, request the one after
@@ -3852,6 +3913,14 @@ extern "C" int rp_nn_resstage16(rp_ctx *ctx, const float *x_dev, const float *fr
         { const int rc_ = allow_lds(ctx, (const void *)k_resstage16<NT_>, lds, "rp_nn_resstage16"); if (rc_ != RP_OK) return rc_; }                \
         hipLaunchKernelGGL((k_resstage16<NT_>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev); \
         break;
+    static const int rs16_tail = getenv("RP_STAGE16_TAIL") ? atoi(getenv("RP_STAGE16_TAIL")) : 1;  // 0: the tail pixels as a whole tile (A/B)
+    const int tail_px = (imgw * PIX) & 15;
+    if (rs16_tail && nt == 7 && tail_px >= 1 && tail_px <= 4) {  // six tiles + a tail of up to four pixels (10x10: 96 + 4)
+        { const int rc_ = allow_lds(ctx, (const void *)k_resstage16<6, true>, lds, "rp_nn_resstage16"); if (rc_ != RP_OK) return rc_; }
+        hipLaunchKernelGGL((k_resstage16<6, true>), grid, block, lds, ctx->stream, x_dev, frag4_dev, bias4_dev, out_dev, out_relu_dev, (long long)B, (int)H, (int)W, imgw, ctx->nn_rows_dev);
+        HIPCHK(ctx, hipGetLastError());
+        return RP_OK;
+    }
     switch (nt) {
         RS_LAUNCH(1) RS_LAUNCH(2) RS_LAUNCH(3) RS_LAUNCH(4) RS_LAUNCH(5) RS_LAUNCH(6) RS_LAUNCH(7) RS_LAUNCH(8)
         default: return fail(ctx, RP_ERR_ARG, "rp_nn_resstage16: unsupported image size");
