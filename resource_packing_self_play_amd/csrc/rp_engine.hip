@@ -2686,9 +2686,18 @@ __host__ __device__ inline int r32_imgp(int H, int W) { return (H + 2) * (W + 1)
 // One 3x3 convolution CIN -> 32 over NT pixel tiles on the padded image.  abase[t]: FLOAT offset of this lane's first channel quad
 // (input channels CIN/4 * g ..) of the top-left tap of tile t's pixel of this lane; wq: fragments of half-taps (0, 1) on entry, of the
 // NEXT convolution's (byte offset fnext) on exit.
-template <int NT, int CIN, int PS = r32_ps(CIN)>
-__device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
-                                         f32x4 (&wq)[3][2]) {
+// Tail tile of up to four pixels for the 32-output-channel convolutions (see RsTail): block (cg, kk) = (lane >> 3, (lane >> 2) & 1)
+// takes output channels 4 cg .. + 3 (eight groups) over the input-channel slice [kk CIN/2, (kk + 1) CIN/2).  Per half-tap (tap, h) the
+// slice's channels (CIN/4)(2 kk + w) + 4 h + j, w = 0, 1, j = 0..3: two 16-byte operand reads, two 16-byte weight pieces -- the ordinary
+// fragments of lane (4 (cg & 3) + (lane & 3)) + 16 (2 kk + w) in M tile cg >> 2 -- and eight 8-cycle MFMAs (64 matrix-pipe cycles
+// against 256 for the tile).  The two kk blocks of a channel group are added in the epilogue (lanes l and l ^ 4).
+// Tail state (kept as separate scalars / vectors: as one struct behind a pointer it stayed in scratch memory):
+//   t_abase  float offset of the lane's tail pixel (lane & 3): top-left tap, first channel of its slice
+//   t_voff0/1  byte offsets of its two weight pieces inside a half-tap's 2 KB
+//   t_w0 / t_w1  [2]: the two pieces of half-taps (s, s + 1) -- one half-tap ahead is enough (a half-tap is >= 1.5 k cycles of MFMAs)
+template <int NT, int CIN, int PS, bool TAIL>
+__device__ __forceinline__ void r32_conv_t(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
+                                           f32x4 (&wq)[3][2], int t_abase, int t_voff0, int t_voff1, f32x4 &t_acc, f32x4 (&t_w0)[2], f32x4 (&t_w1)[2]) {
     constexpr int HQ = CIN / 16, NH = 9 * HQ;  // half-taps per tap, per convolution
     const int voff = lane_id() * 16;
     int z = 0; asm volatile("" : "+v"(z));  // opaque zero: the 9 * NT operand addresses of a convolution must not be hoisted out of the task loop
@@ -2696,12 +2705,21 @@ __device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_
         const int dr = tap / 3, dx = tap - 3 * dr;
         return *(const f32x4 *)(img + abase[t] + z + ((dr * PW + dx) * PS + 4 * h));
     };
-    f32x4 a[NT][HQ];
+    auto at_read = [&](int tap, int h, int w) {  // tail operand: channels (CIN/4)(2 kk + w) + 4 h .. + 3 of the lane's tail pixel
+        const int dr = tap / 3, dx = tap - 3 * dr;
+        return *(const f32x4 *)(img + t_abase + z + ((dr * PW + dx) * PS + (CIN / 4) * w + 4 * h));
+    };
+    f32x4 a[NT][HQ], at[HQ][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < HQ; ++h) a[t][h] = a_read(t, 0, h);
+    }
+    if (TAIL) {
+        t_acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < HQ; ++h) { at[h][0] = at_read(0, h, 0); at[h][1] = at_read(0, h, 1); }
     }
 #pragma unroll
     for (int s = 0; s < NH; ++s) {  // half-tap s = tap * HQ + h
@@ -2728,7 +2746,27 @@ __device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_
             if (tap + 1 < 9) a[t][h] = a_read(t, tap + 1, h);  // this half's fragment of the next tap: first used a whole tap from here
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (TAIL) {
+            const f32x4 wa = t_w0[s % 2], wb = t_w1[s % 2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t_acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[j], at[h][0][j], t_acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t_acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[j], at[h][1][j], t_acc, 0, 0, 0);
+            asm volatile("" : "+v"(t_acc));  // keeps the chain HERE: left alone it sinks behind the convolution with all 18 operand sets alive (93 spills)
+            if (tap + 1 < 9) { at[h][0] = at_read(tap + 1, h, 0); at[h][1] = at_read(tap + 1, h, 1); }
+            {   // this slot is free: the pieces of half-tap s + 2 (first used a whole half-tap from here)
+                const int s2 = s + 2, off = s2 < NH ? fbase + s2 * 2048 : fnext + (s2 - NH) * 2048;
+                t_w0[s % 2] = rs_load_b(frs, t_voff0, off); t_w1[s % 2] = rs_load_b(frs, t_voff1, off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+}
+template <int NT, int CIN, int PS = r32_ps(CIN)>
+__device__ __forceinline__ void r32_conv(const float *img, __amdgpu_buffer_rsrc_t frs, int fbase, int fnext, int PW, const int (&abase)[NT], f32x4 (&acc)[NT][2],
+                                         f32x4 (&wq)[3][2]) {
+    f32x4 d0, d1[2], d2[2];
+    r32_conv_t<NT, CIN, PS, false>(img, frs, fbase, fnext, PW, abase, acc, wq, 0, 0, 0, d0, d1, d2);
 }
 // frag = [4][9][2][2][64] float4, bias = [4][32] in execution order; IMGW leaves per wave, IMGW * PIX <= 16 * NT.  Persistent waves.
 template <int NT>
@@ -2856,7 +2894,7 @@ __global__ void __launch_bounds__(256, 2) k_resstage32(const float *__restrict__
 #ifdef CP_STAMP
 __device__ unsigned long long g_cp_stamp[8];
 #endif
-template <int NT, int CIN>
+template <int NT, int CIN, bool TAIL = false>  // TAIL: NT tiles of 16 pixels + a tail of up to four (R32Tail)
 __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__ x, const float *__restrict__ frag, const float *__restrict__ bias,
                                                        float *__restrict__ out, long long B, int S_h, int S_w, int IMGW, int wave_floats,
                                                        const int *__restrict__ nrows_dev) {
@@ -2868,10 +2906,11 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     if (((long long)blockIdx.x * 4) * IMGW >= B) return;
     const int PW = r32_pw(S_w), PIX = S_h * S_w, IMGP = r32_imgp(S_h, S_w), MP = IMGW * PIX;
     const int Hp = (S_h + 1) >> 1, Wp = (S_w + 1) >> 1, PP = Hp * Wp;
-    int *ptab = (int *)rb_lds;            // [16 * NT] padded pixel index of pixel m
-    int *pool = ptab + 16 * NT;           // [IMGW * PP]: padded index of the window's centre | up << 16 | down << 17 | left << 18 | right << 19
-    float *img = rb_lds + 16 * NT + ((IMGW * PP + 3) & ~3) + (size_t)wv * wave_floats;
-    for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+    constexpr int NTT = NT + (TAIL ? 1 : 0);  // the tables are sized for whole tiles
+    int *ptab = (int *)rb_lds;            // [16 * NTT] padded pixel index of pixel m
+    int *pool = ptab + 16 * NTT;          // [IMGW * PP]: padded index of the window's centre | up << 16 | down << 17 | left << 18 | right << 19
+    float *img = rb_lds + 16 * NTT + ((IMGW * PP + 3) & ~3) + (size_t)wv * wave_floats;
+    for (int i = threadIdx.x; i < 16 * NTT; i += blockDim.x) {
         int im = i / PIX, pq = i - im * PIX, r = pq / S_w, c = pq - r * S_w;
         ptab[i] = i < MP ? im * IMGP + (r + 1) * PW + c + 1 : 0;
     }
@@ -2900,17 +2939,38 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
     const int rowoff = n * (CIN * 4) + g * 16;
     auto task_bytes = [&](long long l0) { return (int)(B - l0 < IMGW ? B - l0 : IMGW) * PIX * CIN * 4; };
     f32x4 xv[NT][XQ], wq[3][2];
+    // tail tile: lane = (channel group cg = lane >> 3, input-channel slice kk = (lane >> 2) & 1, tail pixel lane & 3)
+    int t_abase = 0, t_voff0 = 0, t_voff1 = 0;
+    f32x4 t_acc = (f32x4){0.f, 0.f, 0.f, 0.f}, t_w0[2], t_w1[2];
+    const int cg = lane >> 3, kk = (lane >> 2) & 1, mt = 16 * NT + (lane & 3);
+    int pout_t = 0, pin_t = 0;
+    f32x4 xvt = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int xq_t = (lane >> 2) & (CIN / 4 - 1);  // the lane's 16-byte piece of the tail pixel's x (pieces repeat across the wave: same bytes)
+    const int rowoff_t = (lane & 3) * (CIN * 4) + xq_t * 16;
+    if (TAIL) {
+        const int pc = mt < MP ? ptab[mt] : IMGW * IMGP;
+        t_abase = (ptab[mt < MP ? mt : 0] - (PW + 1)) * PS + (CIN / 2) * kk;
+        const int lw = 4 * (cg & 3) + (lane & 3) + 32 * kk;
+        t_voff0 = (cg >> 2) * 1024 + lw * 16; t_voff1 = (cg >> 2) * 1024 + (lw + 16) * 16;
+        pout_t = pc * PS + 4 * cg;
+        pin_t = pc * PS + 4 * xq_t;
+    }
     auto load_x = [&](long long l0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)l0 * PIX * CIN), 0, task_bytes(l0), RS_BUF_FLAGS);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int q = 0; q < XQ; ++q) xv[t][q] = rs_load_x(rs, rowoff, t * 16 * CIN * 4 + 64 * q);
+        if (TAIL) xvt = rs_load_x(rs, rowoff_t, NT * 16 * CIN * 4);
     };
     const int cq = lane & 7;
     load_x(leaf0);
     wq[0][0] = rs_load_b(frs, lane * 16, 0); wq[0][1] = rs_load_b(frs, lane * 16, 1024);
     wq[1][0] = rs_load_b(frs, lane * 16, 2048); wq[1][1] = rs_load_b(frs, lane * 16, 3072);
+    if (TAIL) {
+        t_w0[0] = rs_load_b(frs, t_voff0, 0); t_w1[0] = rs_load_b(frs, t_voff1, 0);
+        t_w0[1] = rs_load_b(frs, t_voff0, 2048); t_w1[1] = rs_load_b(frs, t_voff1, 2048);
+    }
 #ifdef CP_STAMP  // diagnostic build: per-phase shader-clock totals of all waves (rp_debug_cp_stamp)
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define CP_T(k) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; }
@@ -2923,11 +2983,12 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
         for (int t = 0; t < NT; ++t)  // x (no ReLU in front of a stage's first convolution) into the padded images (zeros past the task's end)
 #pragma unroll
             for (int q = 0; q < XQ; ++q) *(f32x4 *)(img + pin[t] + 16 * q) = xv[t][q];
+        if (TAIL) *(f32x4 *)(img + pin_t) = xvt;
         if (leaf0 + stride_leaves < B) load_x(leaf0 + stride_leaves);
         f32x4 acc[NT][2];
         lds_sync();
         CP_T(0)
-        r32_conv<NT, CIN, PS>(img, frs, 0, 0, PW, abase, acc, wq);
+        r32_conv_t<NT, CIN, PS, TAIL>(img, frs, 0, 0, PW, abase, acc, wq, t_abase, t_voff0, t_voff1, t_acc, t_w0, t_w1);
         CP_T(1)
         lds_sync();
         // convolution output + bias over the interior pixels the convolution has read (rows past the wave's pixels: the dummy pixel)
@@ -2935,6 +2996,15 @@ __global__ void __launch_bounds__(256, 2) k_convpool32(const float *__restrict__
         for (int t = 0; t < NT; ++t) {
             *(f32x4 *)(img + pin[t]) = acc[t][0] + ba;
             *(f32x4 *)(img + pin[t] + 16) = acc[t][1] + bb;
+        }
+        if (TAIL) {  // the two input-channel slices of a channel group meet (lanes l and l ^ 4); the kk = 0 lane writes the quad
+            f32x4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // bias quad cg sits in ba of lane group cg (cg < 4) or bb of lane group cg - 4
+                const float b0 = __shfl(ba[k], 16 * (cg & 3)), b1 = __shfl(bb[k], 16 * (cg & 3));
+                r[k] = (t_acc[k] + __shfl_xor(t_acc[k], 4)) + (cg < 4 ? b0 : b1);
+            }
+            if (kk == 0) *(f32x4 *)(img + pout_t) = r;
         }
         lds_sync();
         CP_T(2)
@@ -3996,7 +4066,12 @@ extern "C" int rp_nn_convpool32(rp_ctx *ctx, const float *x_dev, const float *fr
         hipLaunchKernelGGL((k_convpool32<NT_, CIN_>), grid, block, lds, ctx->stream, x_dev, frag_dev, bias_dev, out_dev, (long long)B, (int)H,        \
                            (int)W, imgw, (int)wf, ctx->nn_rows_dev);                                                                                 \
     }
-    if (Cin == 16) {
+    static const int cp_tail = getenv("RP_CONVPOOL_TAIL") ? atoi(getenv("RP_CONVPOOL_TAIL")) : 1;  // 0: the tail pixels as a whole tile (A/B)
+    const int tail_px = (imgw * PIX) & 15;
+    if (cp_tail && Cin == 16 && nt == 7 && tail_px >= 1 && tail_px <= 4) {  // six tiles + a tail of up to four pixels (10x10: 96 + 4)
+        const int rc_ = allow_lds(ctx, (const void *)k_convpool32<6, 16, true>, lds, "rp_nn_convpool32"); if (rc_ != RP_OK) return rc_;
+        hipLaunchKernelGGL((k_convpool32<6, 16, true>), grid, block, lds, ctx->stream, x_dev, frag_dev, bias_dev, out_dev, (long long)B, (int)H, (int)W, imgw, (int)wf, ctx->nn_rows_dev);
+    } else if (Cin == 16) {
         switch (nt) {
             case 1: CP_LAUNCH(1, 16) break; case 2: CP_LAUNCH(2, 16) break; case 3: CP_LAUNCH(3, 16) break; case 4: CP_LAUNCH(4, 16) break;
             case 5: CP_LAUNCH(5, 16) break; case 6: CP_LAUNCH(6, 16) break; case 7: CP_LAUNCH(7, 16) break;
