@@ -517,7 +517,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--warm-waves", type=int, default=96, help="waves of the short warm-up pass before the first pool")
-    ap.add_argument("--event-every", type=int, default=16, help="take per-phase HIP-event timings every n-th wave")
+    ap.add_argument("--event-every", type=int, default=64, help="take per-phase / per-kernel HIP-event timings every n-th wave (those waves run eagerly between events instead of as one graph launch: 16 cost 0.4 %% of the episodes/s, 64 still time ~190 launches of every kernel per pool)")
     ap.add_argument("--profile-waves", type=int, default=0, help="profiling aid: stop after this many waves per group and print no metric")
     ap.add_argument("--waves", type=int, default=0, help="bounded run for configurations whose pool takes many minutes (c5: ~100 k waves): play this many waves of "
                     "one pool and report expansions/s and simulations/s of that window (no episodes/s: no episode ends inside it)")

@@ -537,7 +537,8 @@ def test_fused_resstage16_kernel_matches_pytorch_blocks():
     frag4, bias4 = net.nnet._dense["stagefrag:0"], net.nnet._dense["stagebias:0"]
     # images above 128 pixels run one workgroup per image (k_resstage16_wg: 4 or 8 waves share the tiles): 25x25 is the 50x50 board's
     # 10x10 (96 + 4 pixels), 9x11 (96 + 3) and 7x14 (96 + 2) take their last pixels through the 4x4x1 tail blocks
-    for (B, H, W) in [(5, 10, 10), (1030, 10, 10), (6, 9, 11), (5, 7, 14), (64, 7, 9), (33, 3, 3), (17, 8, 8), (9, 5, 5), (3, 1, 1), (21, 11, 11), (6, 8, 16), (7, 5, 13),
+    # (8000 leaves of 5x5: four leaves per wave = 96 + 4 pixels: a tail tile across images)
+    for (B, H, W) in [(5, 10, 10), (1030, 10, 10), (6, 9, 11), (5, 7, 14), (8000, 5, 5), (64, 7, 9), (33, 3, 3), (17, 8, 8), (9, 5, 5), (3, 1, 1), (21, 11, 11), (6, 8, 16), (7, 5, 13),
                       (5, 25, 25), (530, 25, 25), (3, 20, 32), (4, 12, 12), (2, 16, 20), (3, 9, 33), (2, 21, 17)]:
         x = torch.randn(B, 16, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
@@ -613,7 +614,7 @@ def test_fused_convpool32_kernel_matches_pytorch_conv_and_pool():
     from resource_packing_self_play_amd import _lib
     eng = _lib.Engine(20, 20, 32, 1, 1, stream=torch.cuda.current_stream().cuda_stream)
     torch.manual_seed(6)
-    cases = [(16, 5, 10, 10), (16, 1030, 10, 10), (16, 6, 9, 11), (16, 5, 7, 14), (16, 33, 7, 9),  # 10x10 / 9x11 / 7x14: 96 pixels + a 4x4x1 tail of 4 / 3 / 2 (16, 9, 3, 3), (16, 4, 1, 1), (16, 21, 8, 13), (16, 64, 4, 4),
+    cases = [(16, 5, 10, 10), (16, 1030, 10, 10), (16, 6, 9, 11), (16, 5, 7, 14), (16, 8000, 5, 5), (16, 33, 7, 9),  # 10x10 / 9x11 / 7x14: 96 pixels + a 4x4x1 tail of 4 / 3 / 2 (16, 9, 3, 3), (16, 4, 1, 1), (16, 21, 8, 13), (16, 64, 4, 4),
              (32, 5, 5, 5), (32, 1030, 5, 5), (32, 3001, 3, 3), (32, 17, 8, 8), (32, 11, 7, 9), (32, 6, 2, 5), (32, 3, 1, 1), (32, 10, 8, 10),
              # above 112 / 80 pixels: k_convpool32_wg (25x25x16 -> 13x13x32 and 13x13x32 -> 7x7x32 at the 50x50 board)
              (16, 5, 25, 25), (16, 300, 25, 25), (16, 3, 12, 12), (16, 4, 20, 31), (16, 2, 9, 33), (32, 7, 13, 13), (32, 500, 13, 13), (32, 4, 16, 16),
